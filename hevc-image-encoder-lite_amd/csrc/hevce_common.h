@@ -1,0 +1,65 @@
+/*
+ * hevce_common.h -- layouts shared by the HIP analysis kernel and the host stream writer.
+ *
+ * Decision record: what the device hands to the host per 32x32 CTU (DESIGN.md "Data layout in HBM").
+ * Context layout : compact index space for the CABAC contexts a luma-only HEVC intra stream touches
+ *                  (the reference's ContextSet, HEVCe.c:745-759, minus its chroma / unused slots).
+ */
+#pragma once
+#include <stdint.h>
+
+#define HEVCE_CTU        32
+#define HEVCE_MAXDIM     8192
+#define HEVCE_NMODES     35
+#define HEVCE_REC_BYTES  2176
+
+enum {
+    CX_SPLIT_CU = 0,   /* 3 */
+    CX_PART     = 3,
+    CX_YPM      = 4,
+    CX_UVPM     = 5,
+    CX_SPLIT_TU = 6,   /* 3 : 32,16,8 */
+    CX_YCBF     = 9,   /* 2 : index = (transform depth == 0) */
+    CX_UVCBF    = 11,
+    CX_LASTX    = 12,  /* 4 size classes x 5 */
+    CX_LASTY    = 32,
+    CX_SIGCG    = 52,  /* 2 */
+    CX_SIG      = 54,  /* 27 (+1 pad) */
+    CX_ONE      = 82,  /* 16 */
+    CX_ABS      = 98,  /* 4 */
+    HEVCE_NCTX  = 102,
+    HEVCE_NCTXP = 104  /* padded */
+};
+
+/* bits of HevceRecord.info */
+#define HEVCE_INFO_LOG2_MASK 3   /* log2(cu size) - 3 */
+#define HEVCE_INFO_NXN       4
+#define HEVCE_INFO_TUSPLIT   8
+
+typedef struct HevceRecord {
+    int16_t lev[32][32];   /* quantised levels, natural position inside the CTU */
+    uint8_t mode[8][8];    /* luma intra mode per 4x4 block */
+    uint8_t info[8][8];    /* CU size / partition / transform split per 4x4 block */
+} HevceRecord;
+
+/* arithmetic-coder registers (reference CABACcoder, HEVCe.c:797-806, without its byte buffer) */
+typedef struct HevceCoderRegs {
+    int32_t  range;
+    uint32_t low;
+    int32_t  nbits, nbytes, bufbyte, zeros;
+    int32_t  nout;   /* bytes produced so far, emulation-prevention bytes included */
+    int32_t  pad;
+} HevceCoderRegs;
+
+/* one image of a batch, as the kernel sees it (all pointers are device pointers) */
+typedef struct HevceImageDesc {
+    const uint8_t *img;       /* src_h x src_w luma, stride src_w */
+    uint8_t       *rcon;      /* H x W reconstruction, stride W */
+    uint8_t       *records;   /* (H/32)*(W/32) HevceRecord, raster CTU order */
+    int32_t       *ctu_state; /* optional: 8 ints per CTU (coder registers after the CTU) */
+    uint8_t       *scratch;   /* HEVCE_SCRATCH_BYTES of per-image trial scratch */
+    int32_t src_h, src_w, H, W, qpd6, status;
+} HevceImageDesc;
+
+#define HEVCE_TRIALS        72                               /* 35 + 35 + 1 (+1 pad) trial slots */
+#define HEVCE_SCRATCH_BYTES (HEVCE_TRIALS * 1024 * 3)        /* int16 levels + u8 reconstruction per trial */

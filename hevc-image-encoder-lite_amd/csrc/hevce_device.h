@@ -1,0 +1,1047 @@
+/*
+ * hevce_device.h -- the per-CTU analysis loop of an HEVC intra still-picture encoder, written for
+ * CDNA4 (gfx950): ONE WORKGROUP (8 wavefronts of 64) WALKS ONE IMAGE'S CTUs in raster order with all
+ * coder / neighbour state resident in LDS.  Bit-exact with lidongxuan/HEVC-image-encoder-lite
+ * (reference src/HEVCe.c); each routine cites the reference lines whose results it reproduces.
+ *
+ * Why one workgroup per image: every RD decision is costed with the live CABAC state, so an image is a
+ * single dependency chain.  Parallelism is taken (a) across images = workgroups,
+ * (b) inside a CU: the 35 prediction modes x {one TU, four TUs, NxN} run as wave-level "TU jobs"
+ * (lane = one column / row of a transform block) and as lane-level trial encodes (lane = one candidate).
+ *
+ * The same source is compiled by tests/emu (HEVCE_EMU) for a CPU fiber emulation used by the CPU test
+ * suite to debug the control flow; that build is test infrastructure and is never part of the library.
+ */
+#pragma once
+#include "hevce_common.h"
+
+#ifdef HEVCE_EMU
+#include "emu_rt.h"
+#else
+#include <hip/hip_runtime.h>
+#define HD  __device__ __forceinline__
+#define HDN __device__ __noinline__
+#define DEVCONST __constant__ const
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define BLOCK_SYNC() __syncthreads()
+static HD int  hv_tid() { return (int)threadIdx.x; }
+static HD int  hv_shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
+static HD int  hv_bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }   /* lane 0's value, wave-uniform (SGPR) */
+static HD int  hv_atomic_inc(int *p) { return atomicAdd(p, 1); }
+static HD int  hv_mul24(int a, int b) { return __mul24(a, b); }
+static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v == 0 */
+#endif
+
+#define HV_NTHREADS 512
+#define HV_NWAVES   8
+#define HV_TL       HEVCE_TRIALS
+#define HV_I32MAX   0x7fffffff
+#define HV_RX       4            /* column offset of x=0 inside Lds::rec rows (x=-1 lives at column 3) */
+
+typedef unsigned char  u8;
+typedef unsigned short u16;
+typedef unsigned long long u64;
+
+/* --------------------------------------------------------------------------------------------- */
+/* compile-time tables                                                                             */
+/* --------------------------------------------------------------------------------------------- */
+struct HvTMats {
+    int f4[16], f8[64], f16[256], f32[1024];   /* C[k][n]  (k = frequency)             */
+    int t4[16], t8[64], t16[256], t32[1024];   /* C^T : t[n][k] = C[k][n]              */
+};
+constexpr int hv_basis(int k, int n) {          /* HEVC core transform entry, 32-point   [ref HEVCe.c:431-464] */
+    constexpr int mag[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                              61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+    if (k == 0) return 64;
+    int m = (k * (2 * n + 1)) & 127;
+    if (m > 64) m = 128 - m;
+    return m > 32 ? -mag[64 - m] : mag[m];
+}
+constexpr HvTMats hv_make_tmats() {
+    HvTMats t{};
+    constexpr int dst[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };   /* [ref HEVCe.c:391-396] */
+    for (int k = 0; k < 4; k++) for (int n = 0; n < 4; n++) { t.f4[k * 4 + n] = dst[k * 4 + n]; t.t4[n * 4 + k] = dst[k * 4 + n]; }
+    for (int k = 0; k < 8; k++) for (int n = 0; n < 8; n++) { t.f8[k * 8 + n] = hv_basis(4 * k, n); t.t8[n * 8 + k] = hv_basis(4 * k, n); }
+    for (int k = 0; k < 16; k++) for (int n = 0; n < 16; n++) { t.f16[k * 16 + n] = hv_basis(2 * k, n); t.t16[n * 16 + k] = hv_basis(2 * k, n); }
+    for (int k = 0; k < 32; k++) for (int n = 0; n < 32; n++) { t.f32[k * 32 + n] = hv_basis(k, n); t.t32[n * 32 + k] = hv_basis(k, n); }
+    return t;
+}
+DEVCONST HvTMats hv_tm = hv_make_tmats();
+
+/* H.265 table 9-46 (rangeTabLps), four bytes per state packed little-endian; table 9-47 (transIdxLps) */
+DEVCONST unsigned hv_lps4[64] = {
+    0xf0d0b080u, 0xe3c5a780u, 0xd8bb9e80u, 0xcdb2967bu, 0xc3a98e74u, 0xb9a0876fu, 0xaf988069u, 0xa6907a64u,
+    0x9e89745fu, 0x96826e5au, 0x8e7b6855u, 0x87756351u, 0x806f5e4du, 0x7a695949u, 0x74645545u, 0x6e5f5042u,
+    0x685a4c3eu, 0x6356483bu, 0x5e514538u, 0x594d4135u, 0x55493e33u, 0x50453b30u, 0x4c42382eu, 0x483f352bu,
+    0x453b3229u, 0x41383027u, 0x3e362d25u, 0x3b332b23u, 0x38302921u, 0x352e2720u, 0x322b251eu, 0x3029231du,
+    0x2d27211bu, 0x2b251f1au, 0x29231e18u, 0x27211c17u, 0x25201b16u, 0x231e1a15u, 0x211d1814u, 0x1f1b1713u,
+    0x1e1a1612u, 0x1c191511u, 0x1b171410u, 0x1916130fu, 0x1815120eu, 0x1714110eu, 0x1613100du, 0x15120f0cu,
+    0x14110e0cu, 0x13100e0bu, 0x120f0d0bu, 0x110f0c0au, 0x100e0c0au, 0x0f0d0b09u, 0x0e0c0b09u, 0x0e0c0a08u,
+    0x0d0b0908u, 0x0c0b0907u, 0x0c0a0907u, 0x0b0a0807u, 0x0b090806u, 0x0a090706u, 0x09080706u, 0x02020202u };
+DEVCONST u8 hv_lpsnext[64] = {
+     0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9,11,11,12,13,13,15,15,16,16,18,18,19,19,21,21,22,22,23,24,
+    24,25,26,26,27,27,28,29,29,30,30,30,31,32,32,33,33,33,34,34,35,35,35,36,36,36,37,37,37,38,38,63 };
+/* H.265 9.3.2.2 initValue (I slices) in the compact layout of hevce_common.h  [ref HEVCe.c:763-777] */
+DEVCONST u8 hv_ctxinit[HEVCE_NCTXP] = {
+    139, 141, 157, 184, 184, 63, 153, 138, 138, 111, 141, 94,
+    110, 110, 124, 0, 0, 125, 140, 153, 0, 0, 125, 127, 140, 109, 0, 111, 143, 127, 111, 79,
+    110, 110, 124, 0, 0, 125, 140, 153, 0, 0, 125, 127, 140, 109, 0, 111, 143, 127, 111, 79,
+    91, 171,
+    111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 0,
+    140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152,
+    138, 153, 136, 167, 0, 0 };
+DEVCONST signed char hv_ang[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
+                                    -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+DEVCONST short hv_invang[35] = { 0, 0, 256, 315, 390, 482, 630, 910, 1638, 4096, 0, 4096, 1638, 910, 630, 482,
+                                 390, 315, 256, 315, 390, 482, 630, 910, 1638, 4096, 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
+DEVCONST u8 hv_lastgrp[32] = { 0,1,2,3,4,4,5,5,6,6,6,6,7,7,7,7,8,8,8,8,8,8,8,8,9,9,9,9,9,9,9,9 };
+DEVCONST u8 hv_lastmin[10] = { 0, 1, 2, 3, 4, 6, 8, 12, 16, 24 };
+DEVCONST u8 hv_sig4[16]    = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };
+DEVCONST u8 hv_sigpos[8]   = { 2, 1, 1, 0, 0, 0, 0, 0 };
+
+/* --------------------------------------------------------------------------------------------- */
+/* LDS image                                                                                       */
+/* --------------------------------------------------------------------------------------------- */
+struct HvTuInfo { u64 cgsig; int last; int cbf; };          /* per (trial, TU): 8x8 bitmap of non-zero 4x4 groups */
+
+struct HvWaveScr {                                          /* private to one wavefront */
+    short scr[64 * 34];                                     /* [slot][row][N+2]: transposition buffer           */
+    u8    pred[64 * 32];                                    /* [slot][row][N] prediction                        */
+    u8    bord[672];                                        /* [slot][raw|smoothed][4N+4] reference samples     */
+    u8    crec[4096];                                       /* [slot][n][n] partial CU reconstruction (TU-split chains) */
+};
+
+struct alignas(16) HvLds {
+    /* tables (copied from constant memory so that per-lane divergent lookups are LDS reads) */
+    unsigned lps4[64];
+    u8  lpsnext[64];
+    u8  d4pos[16], d4idx[16];                               /* diagonal scan inside a 4x4 group: idx->(y<<2|x), (y<<2|x)->idx */
+    u8  cgpos[3][64], cgidx[3][64];                         /* group order for 2x2 / 4x4 / 8x8 groups: idx->(gy<<3|gx), gy*ncg+gx->idx */
+    u8  ctx_fresh[HEVCE_NCTXP];
+    /* committed coder state, entry snapshots per CU level (0: 8x8, 1: 16x16, 2: 32x32) */
+    HevceCoderRegs com, ent[3];
+    u8  com_ctx[HEVCE_NCTXP], ent_ctx[3][HEVCE_NCTXP];
+    /* current CTU */
+    u8  org[32][32];
+    u8  rec[33][72];                                        /* row 0 = y-1, column HV_RX-1 = x-1; 64+1 columns used */
+    u8  map_cu[9][12], map_pm[9][12];                       /* [1+i][1+j]; row 0 / column 0 = neighbours */
+    u8  line_rec[HEVCE_MAXDIM + 64];                        /* bottom row of the CTU row above */
+    u8  line_cu[HEVCE_MAXDIM / 4];
+    int corner_next;
+    /* trials */
+    u8  tctx[HEVCE_NCTXP][HV_TL];
+    HevceCoderRegs tregs[HV_TL];
+    int tcost[HV_TL], tsse[HV_TL];
+    HvTuInfo tinfo[HV_TL][4];
+    short cgbuf[HV_TL][16], absbuf[HV_TL][16];
+    /* NxN sub-search */
+    short nxn_lev[35][16];
+    u8    nxn_rec[35][16];
+    int   nxn_sse[35], nxn_last[35], nxn_sig[35];
+    short nxn_bestlev[4][16];
+    u8    nxn_crec[8][8];
+    int   nxn_modes[4];
+    /* control */
+    int jobctr, winner, split_sse;
+    HvWaveScr ws[HV_NWAVES];
+};
+
+struct HvCod { int range; unsigned low; int nbits, nbytes, bufbyte, zeros, nout; };
+
+/* --------------------------------------------------------------------------------------------- */
+/* small helpers                                                                                   */
+/* --------------------------------------------------------------------------------------------- */
+static HD int hv_min(int a, int b) { return a < b ? a : b; }
+static HD int hv_max(int a, int b) { return a > b ? a : b; }
+static HD int hv_abs(int a) { return a < 0 ? -a : a; }
+static HD int hv_clip16(int v) { return hv_min(hv_max(v, -32768), 32767); }
+static HD int hv_clip8(int v) { return hv_min(hv_max(v, 0), 255); }
+
+/* [ref HEVCe.c:177-185] */
+static HD int hv_rdcost(int q, int dist, int bits) {
+    const int wd = (q < 3) ? 11 : (q == 3 ? 5 : 1);
+    const int wb = (q == 0) ? 1 : (q == 1) ? 4 : (q == 2) ? 16 : (q == 3) ? 29 : 23;
+    const int a = (HV_I32MAX / wd <= dist) ? HV_I32MAX : wd * dist;
+    const int b = (HV_I32MAX / wb <= bits) ? HV_I32MAX : wb * bits;
+    return (HV_I32MAX - a <= b) ? HV_I32MAX : a + b;
+}
+
+/* scan order  [ref HEVCe.c:1127-1151]: kind 0 diagonal, 1 horizontal, 2 vertical (the latter two only for 4x4 / 8x8) */
+static HD int hv_scan_kind(int n, int mode) {
+    if (n <= 8) { if (hv_abs(mode - 26) <= 4) return 1; if (hv_abs(mode - 10) <= 4) return 2; }
+    return 0;
+}
+/* lg = log2(n); tables index lg-3 for 8,16,32; a 4x4 block is a single group */
+static HD int hv_scan_idx(const HvLds &S, int lg, int kind, int y, int x) {
+    const int gy = y >> 2, gx = x >> 2, iy = y & 3, ix = x & 3;
+    if (kind == 1) return ((gy * 2 + gx) << 4) + iy * 4 + ix;
+    if (kind == 2) return ((gx * 2 + gy) << 4) + ix * 4 + iy;
+    const int cg = (lg == 2) ? 0 : S.cgidx[lg - 3][(gy << (lg - 2)) + gx];
+    return (cg << 4) + S.d4idx[(iy << 2) | ix];
+}
+static HD void hv_scan_cg(const HvLds &S, int lg, int kind, int cg, int &gy, int &gx) {
+    if (lg == 2) { gy = 0; gx = 0; }
+    else if (kind == 1) { gy = cg >> 1; gx = cg & 1; }
+    else if (kind == 2) { gx = cg >> 1; gy = cg & 1; }
+    else { const int p = S.cgpos[lg - 3][cg]; gy = p >> 3; gx = p & 7; }
+}
+static HD void hv_scan_in(const HvLds &S, int kind, int ii, int &iy, int &ix) {
+    if (kind == 1) { iy = ii >> 2; ix = ii & 3; }
+    else if (kind == 2) { ix = ii >> 2; iy = ii & 3; }
+    else { const int p = S.d4pos[ii]; iy = p >> 2; ix = p & 3; }
+}
+
+/* --------------------------------------------------------------------------------------------- */
+/* arithmetic coder in counting mode (registers only)  [ref HEVCe.c:797-933]                       */
+/* --------------------------------------------------------------------------------------------- */
+static HD void hv_cod_load(HvCod &c, const HevceCoderRegs &r) {
+    c.range = r.range; c.low = r.low; c.nbits = r.nbits; c.nbytes = r.nbytes; c.bufbyte = r.bufbyte; c.zeros = r.zeros; c.nout = r.nout;
+}
+static HD void hv_cod_store(HevceCoderRegs &r, const HvCod &c) {
+    r.range = c.range; r.low = c.low; r.nbits = c.nbits; r.nbytes = c.nbytes; r.bufbyte = c.bufbyte; r.zeros = c.zeros; r.nout = c.nout; r.pad = 0;
+}
+static HD void hv_cod_fresh(HvCod &c) { c.range = 510; c.low = 0; c.nbits = 23; c.nbytes = 0; c.bufbyte = 0xff; c.zeros = 0; c.nout = 0; }
+static HD int  hv_cod_bits(const HvCod &c) { return 8 * (c.nout + c.nbytes) + 23 - c.nbits; }            /* [ref :835-837] */
+static HD int  hv_regs_bits(const HevceCoderRegs &c) { return 8 * (c.nout + c.nbytes) + 23 - c.nbits; }
+
+static HD void hv_cod_out(HvCod &c, int byte) {                                                            /* [ref :821-832] */
+    byte &= 0xff;
+    if (c.zeros >= 2 && byte <= 3) { c.nout++; c.zeros = 0; }      /* emulation-prevention byte */
+    c.nout++;
+    c.zeros = byte ? 0 : c.zeros + 1;
+}
+static HD void hv_cod_carry(HvCod &c) {                                                                    /* [ref :859-879] */
+    if (c.nbits < 12) {
+        const int lead = (int)(c.low >> (24 - c.nbits));
+        c.nbits += 8;
+        c.low &= 0xffffffffu >> c.nbits;
+        if (lead == 0xff) {
+            c.nbytes++;
+        } else if (c.nbytes > 0) {
+            const int carry = lead >> 8, fill = (0xff + carry) & 0xff;
+            hv_cod_out(c, c.bufbyte + carry);
+            c.bufbyte = lead & 0xff;
+            for (; c.nbytes > 1; c.nbytes--) hv_cod_out(c, fill);
+        } else {
+            c.nbytes = 1; c.bufbyte = lead;
+        }
+    }
+}
+/* context-coded bin; cx points at this trial's context byte  [ref :914-933] */
+static HD void hv_bin(const HvLds &S, HvCod &c, u8 *cx, int bin) {
+    const int v = *cx, st = v >> 1, mps = v & 1;
+    const int lps = (int)((S.lps4[st] >> (((c.range >> 6) & 3) << 3)) & 0xff);
+    c.range -= lps;
+    if ((bin != 0) != (mps != 0)) {
+        const int sh = (lps < 8) ? 6 : hv_clz((unsigned)(lps >> 3)) - 26;       /* renormalisation shift 6..1 */
+        *cx = (u8)(st == 0 ? (mps ^ 1) : ((S.lpsnext[st] << 1) | mps));
+        c.low = (c.low + (unsigned)c.range) << sh;
+        c.range = lps << sh;
+        c.nbits -= sh;
+    } else {
+        if (st < 62) *cx = (u8)(v + 2);
+        if (c.range < 256) { c.low <<= 1; c.range <<= 1; c.nbits--; }
+    }
+    hv_cod_carry(c);
+}
+static HD void hv_bypass(HvCod &c, int bins, int len) {                                                    /* [ref :899-911] */
+    bins &= (1 << len) - 1;
+    while (len > 0) {
+        const int n = hv_min(len, 8);
+        len -= n;
+        c.low = (c.low << n) + (unsigned)c.range * (unsigned)((bins >> len) & ((1 << n) - 1));
+        c.nbits -= n;
+        hv_cod_carry(c);
+    }
+}
+static HD void hv_terminate(HvCod &c, int bin) {                                                           /* [ref :882-896] */
+    c.range -= 2;
+    if (bin) { c.low = (c.low + (unsigned)c.range) << 7; c.range = 256; c.nbits -= 7; }
+    else if (c.range < 256) { c.low <<= 1; c.range <<= 1; c.nbits--; }
+    hv_cod_carry(c);
+}
+
+/* --------------------------------------------------------------------------------------------- */
+/* syntax elements of a trial; cx = &S.tctx[0][slot], contexts are HV_TL apart                      */
+/* --------------------------------------------------------------------------------------------- */
+#define HV_CX(i) (cx + (i) * HV_TL)
+
+static HD void hv_mpm(int left, int above, int out[3]) {                                                   /* [ref :958-977] */
+    if (left != above) {
+        out[0] = left; out[1] = above;
+        out[2] = (left != 0 && above != 0) ? 0 : (left + above < 2 ? 26 : 1);
+    } else if (left > 1) {
+        out[0] = left; out[1] = ((left + 29) & 31) + 2; out[2] = ((left - 1) & 31) + 2;
+    } else { out[0] = 0; out[1] = 1; out[2] = 26; }
+}
+/* prev_intra_luma_pred_flag for every part first, then mpm_idx / rem_intra_luma_pred_mode  [ref :985-1018] */
+static HD void hv_put_modes(const HvLds &S, HvCod &c, u8 *cx, int parts, const int *mode, const int *left, const int *above) {
+    int hit[4], rem[4];
+    for (int i = 0; i < parts; i++) {
+        int p[3];
+        hv_mpm(left[i], above[i], p);
+        int h = -1;
+        for (int j = 0; j < 3; j++) if (p[j] == mode[i]) h = j;
+        hit[i] = h;
+        /* descending sort of the three candidates, then skip them */
+        int a = p[0], b = p[1], d = p[2], t;
+        if (a < b) { t = a; a = b; b = t; }
+        if (b < d) { t = b; b = d; d = t; }
+        if (a < b) { t = a; a = b; b = t; }
+        int r = mode[i];
+        if (r > a) r--;
+        if (r > b) r--;
+        if (r > d) r--;
+        rem[i] = r;
+        hv_bin(S, c, HV_CX(CX_YPM), h >= 0);
+    }
+    for (int i = 0; i < parts; i++) {
+        if (hit[i] >= 0) {
+            hv_bypass(c, hit[i] > 0, 1);
+            if (hit[i] > 0) hv_bypass(c, hit[i] - 1, 1);
+        } else hv_bypass(c, rem[i], 5);
+    }
+}
+
+static HD void hv_put_last(const HvLds &S, HvCod &c, u8 *cx, int n, int lg, int swap, int y, int x) {     /* [ref :1046-1087] */
+    const int cls = lg - 2, sh = (n == 4) ? 0 : 1;
+    int ty = swap ? x : y, tx = swap ? y : x;
+    const int gy = hv_lastgrp[ty], gx = hv_lastgrp[tx], gmax = hv_lastgrp[n - 1];
+    for (int i = 0; i < gx; i++) hv_bin(S, c, HV_CX(CX_LASTX + 5 * cls + (i >> sh)), 1);
+    if (gx < gmax)               hv_bin(S, c, HV_CX(CX_LASTX + 5 * cls + (gx >> sh)), 0);
+    for (int i = 0; i < gy; i++) hv_bin(S, c, HV_CX(CX_LASTY + 5 * cls + (i >> sh)), 1);
+    if (gy < gmax)               hv_bin(S, c, HV_CX(CX_LASTY + 5 * cls + (gy >> sh)), 0);
+    if (gx > 3) { tx -= hv_lastmin[gx]; for (int i = ((gx - 2) >> 1) - 1; i >= 0; i--) hv_bypass(c, (tx >> i) & 1, 1); }
+    if (gy > 3) { ty -= hv_lastmin[gy]; for (int i = ((gy - 2) >> 1) - 1; i >= 0; i--) hv_bypass(c, (ty >> i) & 1, 1); }
+}
+
+static HD int hv_sigctx(int n, int diag, int y, int x, int nb) {                                           /* [ref :1092-1122] */
+    if ((y | x) == 0) return 0;
+    if (n == 4) return hv_sig4[(y << 2) | x];
+    int base = 9;
+    if (n >= 16) base += 12;
+    if (n == 8 && !diag) base += 6;
+    if ((y >> 2) | (x >> 2)) base += 3;
+    const int iy = y & 3, ix = x & 3;
+    if (nb == 0) return base + hv_sigpos[iy + ix];
+    if (nb == 1) return base + hv_sigpos[iy << 1];
+    if (nb == 2) return base + hv_sigpos[ix << 1];
+    return base + 2;
+}
+
+static HD void hv_put_remainder(HvCod &c, int v, int k) {                                                  /* [ref :1154-1169] */
+    if (v < (3 << k)) {
+        const int pre = v >> k;
+        hv_bypass(c, (1 << (pre + 1)) - 2, pre + 1);
+        hv_bypass(c, v & ((1 << k) - 1), k);
+    } else {
+        int len = k;
+        v -= 3 << k;
+        for (; v >= (1 << len); len++) v -= 1 << len;
+        const int t = 4 + len - k;
+        hv_bypass(c, (1 << t) - 2, t);
+        hv_bypass(c, v, len);
+    }
+}
+
+/* residual_coding() of one luma TU whose levels are stored in SCAN ORDER at lev[0..n*n)   [ref :1173-1269]
+   last / cgsig come from the TU job that produced the levels; slot selects the lane-private staging rows */
+static HD void hv_put_residual(HvLds &S, HvCod &c, u8 *cx, int slot, int n, int lg, int mode,
+                               const short *lev, int last, u64 cgsig) {
+    const int kind = hv_scan_kind(n, mode), ncg = n >> 2;
+    short *buf = S.cgbuf[slot], *absv = S.absbuf[slot];
+    int gy = 0, gx = 0, iy, ix;
+    hv_scan_cg(S, lg, kind, last >> 4, gy, gx);
+    hv_scan_in(S, kind, last & 15, iy, ix);
+    hv_put_last(S, c, cx, n, lg, kind == 2, gy * 4 + iy, gx * 4 + ix);
+
+    int nz = 0, signs = 0, nb = 0, c1 = 1, cgs = 0, first_cg = 0;
+    for (int i = last; i >= 0; i--) {
+        const int ii = i & 15;
+        const int at_last = (i == last), cg_first = (ii == 0), cg_enter = (ii == 15) || at_last;
+        if (cg_enter) {
+            const int cg = i >> 4;
+            hv_scan_cg(S, lg, kind, cg, gy, gx);
+            first_cg = (cg == 0);
+            cgs = (int)((cgsig >> (gy * 8 + gx)) & 1);
+            const int right = (gx < ncg - 1) ? (int)((cgsig >> (gy * 8 + gx + 1)) & 1) : 0;
+            const int below = (gy < ncg - 1) ? (int)((cgsig >> (gy * 8 + 8 + gx)) & 1) : 0;
+            nb = (below << 1) | right; nz = 0; signs = 0;
+            if (!first_cg && !at_last) hv_bin(S, c, HV_CX(CX_SIGCG + (nb != 0)), cgs);
+            if (cgs) {
+                const short *src = lev + (cg << 4);
+                for (int k = 0; k < 16; k++) buf[k] = src[k];
+            } else if (!first_cg) {
+                i = cg << 4;          /* an all-zero group that is not the first one carries no further bins */
+                continue;
+            }
+        }
+        const int v = cgs ? buf[ii] : 0;
+        if (!at_last && (first_cg || (cgs && (!cg_first || nz > 0)))) {
+            hv_scan_in(S, kind, ii, iy, ix);
+            hv_bin(S, c, HV_CX(CX_SIG + hv_sigctx(n, kind == 0, gy * 4 + iy, gx * 4 + ix, nb)), v != 0);
+        }
+        if (v) { absv[nz++] = (short)hv_abs(v); signs = (signs << 1) | (v < 0); }
+        if (cg_first && nz > 0) {
+            const int set = (first_cg ? 0 : 2) + (c1 == 0);
+            int esc = nz > 8, g2 = -1;
+            c1 = 1;
+            for (int j = 0; j < 8 && j < nz; j++) {
+                const int a = absv[j];
+                hv_bin(S, c, HV_CX(CX_ONE + 4 * set + c1), a > 1);
+                if (a > 1) { c1 = 0; if (g2 < 0) g2 = a > 2; else esc = 1; }
+                else if (c1 > 0 && c1 < 3) c1++;
+            }
+            if (c1 == 0 && g2 >= 0) { hv_bin(S, c, HV_CX(CX_ABS + set), g2); esc |= g2; }
+            hv_bypass(c, signs, nz);
+            if (esc) {
+                int base = 3, rice = 0;
+                for (int j = 0; j < nz; j++) {
+                    const int a = absv[j], rem = a - (j < 8 ? base : 1);
+                    if (rem >= 0) {
+                        hv_put_remainder(c, rem, rice);
+                        if (a > (3 << rice)) rice = hv_min(rice + 1, 4);
+                    }
+                    if (a >= 2) base = 2;
+                }
+            }
+        }
+    }
+}
+
+/* coding_unit() after split_cu_flag: kind 0 = one TU, 1 = four TUs, 2 = NxN   [ref :1272-1340] */
+static HD void hv_put_cu(HvLds &S, HvCod &c, u8 *cx, int slot, int n, int lg, int kind,
+                         const int *mode, const int *left, const int *above,
+                         const short *lev0, int lev_step, const HvTuInfo *info) {
+    if (n == 8) hv_bin(S, c, HV_CX(CX_PART), kind != 2);
+    hv_put_modes(S, c, cx, kind == 2 ? 4 : 1, mode, left, above);
+    hv_bin(S, c, HV_CX(CX_UVPM), 0);
+    if (kind != 2) hv_bin(S, c, HV_CX(CX_SPLIT_TU + (5 - lg)), kind == 1);
+    hv_bin(S, c, HV_CX(CX_UVCBF), 0);
+    hv_bin(S, c, HV_CX(CX_UVCBF), 0);
+    if (kind == 0) {
+        hv_bin(S, c, HV_CX(CX_YCBF + 1), info[0].cbf);
+        if (info[0].cbf) hv_put_residual(S, c, cx, slot, n, lg, mode[0], lev0, info[0].last, info[0].cgsig);
+    } else {
+        for (int s = 0; s < 4; s++) {
+            hv_bin(S, c, HV_CX(CX_YCBF + 0), info[s].cbf);
+            if (info[s].cbf)
+                hv_put_residual(S, c, cx, slot, n >> 1, lg - 1, mode[kind == 2 ? s : 0], lev0 + s * lev_step, info[s].last, info[s].cgsig);
+        }
+    }
+}
+
+/* --------------------------------------------------------------------------------------------- */
+/* quantiser  [ref HEVCe.c:526-595]                                                                 */
+/* --------------------------------------------------------------------------------------------- */
+static HD int hv_level_rate(int lv) {                                                                      /* [ref :526-535] */
+    if (lv < 6) return lv == 0 ? 0 : lv == 1 ? 70000 : lv == 2 ? 90000 : lv == 3 ? 92000 : lv == 4 ? 157536 : 190304;
+    const int i = 31 - hv_clz((unsigned)(lv - 5));        /* Exp-Golomb prefix length of lv-6 */
+    return 92000 + ((4 + 2 * i) << 15);
+}
+/* returns the level magnitude; d = scaled magnitude used by the group zero-out test */
+static HD int hv_quant1(int q, int sh, int dsh, int av, int &d) {
+    const int half = 1 << sh >> 1, dmax = HV_I32MAX - half;
+    d = (av > 0x1ffff) ? dmax : hv_min((av & 0x1ffff) << 14, dmax);
+    const int lv0 = hv_clip16((d + half) >> sh);
+    const int lo = hv_max(0, lv0 - 2);
+    int best = HV_I32MAX, pick = 0;
+    for (int t = 0; t < 3; t++) {
+        const int lv = lv0 - t;
+        if (lv >= lo) {
+            const int e = hv_abs(d - (lv << sh)) >> dsh;
+            const int dist = ((e < 46340) ? e * e : HV_I32MAX) >> 7;
+            const int cst = hv_rdcost(q, dist, hv_level_rate(lv));
+            if (cst < best) { best = cst; pick = lv; }
+        }
+    }
+    return pick;
+}
+
+/* --------------------------------------------------------------------------------------------- */
+/* TU job: 64/N candidate modes of one NxN transform block per wavefront                            */
+/*   lane = slot*N + j ; j is the COLUMN it owns in column passes and the ROW it owns in row passes  */
+/* --------------------------------------------------------------------------------------------- */
+template <int N> struct HvTm;
+template <> struct HvTm<4>  { static HD const int *f() { return hv_tm.f4;  } static HD const int *t() { return hv_tm.t4;  } enum { LG = 2 }; };
+template <> struct HvTm<8>  { static HD const int *f() { return hv_tm.f8;  } static HD const int *t() { return hv_tm.t8;  } enum { LG = 3 }; };
+template <> struct HvTm<16> { static HD const int *f() { return hv_tm.f16; } static HD const int *t() { return hv_tm.t16; } enum { LG = 4 }; };
+template <> struct HvTm<32> { static HD const int *f() { return hv_tm.f32; } static HD const int *t() { return hv_tm.t32; } enum { LG = 5 }; };
+
+struct HvTuOut { int sse, last, cbf; u64 cgsig; };          /* block-wide values, identical in all lanes of a slot */
+
+/* reconstructed sample at CTU-relative (yy,xx): inside the CU under trial it comes from `inner` */
+static HD int hv_px(const HvLds &S, const u8 *inner, int cu_y, int cu_x, int cu_n, int yy, int xx) {
+    if (inner && yy >= cu_y && yy < cu_y + cu_n && xx >= cu_x && xx < cu_x + cu_n)
+        return inner[(yy - cu_y) * cu_n + (xx - cu_x)];
+    return S.rec[yy + 1][xx + HV_RX];
+}
+/* which (size, mode) pairs read the smoothed reference samples  [ref HEVCe.c:274-280] */
+static HD int hv_smoothed(int n, int m) {
+    if (n == 4 || m == 1) return 0;
+    if (m == 0) return 1;
+    const int d = hv_min(hv_abs(m - 10), hv_abs(m - 26));
+    return n == 8 ? d > 7 : n == 16 ? d > 1 : d > 0;
+}
+
+template <int N>
+static HD HvTuOut hv_tu_job(HvLds &S, HvWaveScr &W, int lane, int q,
+                            int ty, int tx,                         /* block origin, CTU-relative            */
+                            int cu_y, int cu_x, int cu_n, const u8 *inner,
+                            int aL, int aLB, int aA, int aAR,       /* neighbour availability                */
+                            int mode,                               /* this slot's mode, or -1 (idle slot)   */
+                            short *lev_dst,                         /* N*N levels in scan order (per slot)   */
+                            u8 *rec_dst, int rec_stride) {          /* reconstruction (per slot)             */
+    constexpr int LG = HvTm<N>::LG, RS = N + 2, BS = 4 * N + 4;
+    const int slot = lane / N, j = lane % N;
+    const int m = mode < 0 ? 1 : mode;
+    short *scr = W.scr + slot * N * RS;
+    u8 *pred = W.pred + slot * N * N;
+    u8 *braw = W.bord + slot * 2 * BS, *bsm = braw + BS;         /* [0] corner, [1..2N] left, [1+2N..4N] above */
+
+    /* ---- reference samples  [ref HEVCe.c:196-257] ---- */
+    {
+        int corner;
+        if (aL && aA)  corner = hv_px(S, inner, cu_y, cu_x, cu_n, ty - 1, tx - 1);
+        else if (aL)   corner = hv_px(S, inner, cu_y, cu_x, cu_n, ty, tx - 1);
+        else if (aA)   corner = hv_px(S, inner, cu_y, cu_x, cu_n, ty - 1, tx);
+        else           corner = 128;
+        const int l0 = aL ? hv_px(S, inner, cu_y, cu_x, cu_n, ty + j, tx - 1) : corner;
+        const int a0 = aA ? hv_px(S, inner, cu_y, cu_x, cu_n, ty - 1, tx + j) : corner;
+        int l1, a1;
+        if (aLB) l1 = hv_px(S, inner, cu_y, cu_x, cu_n, ty + N + j, tx - 1);
+        else     l1 = aL ? hv_px(S, inner, cu_y, cu_x, cu_n, ty + N - 1, tx - 1) : corner;
+        if (aAR) a1 = hv_px(S, inner, cu_y, cu_x, cu_n, ty - 1, tx + N + j);
+        else     a1 = aA ? hv_px(S, inner, cu_y, cu_x, cu_n, ty - 1, tx + N - 1) : corner;
+        if (j == 0) braw[0] = (u8)corner;
+        braw[1 + j] = (u8)l0; braw[1 + N + j] = (u8)l1;
+        braw[1 + 2 * N + j] = (u8)a0; braw[1 + 3 * N + j] = (u8)a1;
+    }
+    WAVE_SYNC();
+    {
+        const u8 *l = braw + 1, *a = braw + 1 + 2 * N;
+        const int c = braw[0];
+        if (j == 0) {
+            bsm[0] = (u8)((2 + l[0] + a[0] + 2 * c) >> 2);
+            bsm[1] = (u8)((2 + 2 * l[0] + l[1] + c) >> 2);
+            bsm[1 + 2 * N] = (u8)((2 + 2 * a[0] + a[1] + c) >> 2);
+        } else {
+            bsm[1 + j] = (u8)((2 + 2 * l[j] + l[j - 1] + l[j + 1]) >> 2);
+            bsm[1 + 2 * N + j] = (u8)((2 + 2 * a[j] + a[j - 1] + a[j + 1]) >> 2);
+        }
+        const int k = N + j;
+        if (j == N - 1) { bsm[1 + k] = l[k]; bsm[1 + 2 * N + k] = a[k]; }
+        else {
+            bsm[1 + k] = (u8)((2 + 2 * l[k] + l[k - 1] + l[k + 1]) >> 2);
+            bsm[1 + 2 * N + k] = (u8)((2 + 2 * a[k] + a[k - 1] + a[k + 1]) >> 2);
+        }
+    }
+    /* DC value of every slot (wave-uniform code: shuffles must not sit in the per-mode branches) */
+    int dcsum = braw[1 + j] + braw[1 + 2 * N + j];
+    for (int s = 1; s < N; s <<= 1) dcsum += hv_shfl_xor(dcsum, s);
+    WAVE_SYNC();
+
+    /* ---- prediction of column j  [ref HEVCe.c:262-381]; residual goes to scr, prediction to pred ---- */
+    {
+        const u8 *b = hv_smoothed(N, m) ? bsm : braw;
+        const u8 *l = b + 1, *a = b + 1 + 2 * N;
+        const int c = b[0];
+        const bool edge = N <= 16;
+        const int ox = tx + j;
+        if (m == 0) {
+            const int aj = a[j], lN = l[N], aN = a[N];
+            for (int i = 0; i < N; i++) {
+                const int p = (N + (N - 1 - j) * l[i] + (j + 1) * aN + (N - 1 - i) * aj + (i + 1) * lN) >> (LG + 1);
+                pred[i * N + j] = (u8)p; scr[i * RS + j] = (short)((int)S.org[ty + i][ox] - p);
+            }
+        } else if (m == 1) {
+            const int dc = (dcsum + N) >> (LG + 1);
+            for (int i = 0; i < N; i++) {
+                int p = dc;
+                if (edge) {
+                    if (i == 0 && j == 0) p = (2 + 2 * dc + l[0] + a[0]) >> 2;
+                    else if (i == 0)      p = (2 + 3 * dc + a[j]) >> 2;
+                    else if (j == 0)      p = (2 + 3 * dc + l[i]) >> 2;
+                }
+                pred[i * N + j] = (u8)p; scr[i * RS + j] = (short)((int)S.org[ty + i][ox] - p);
+            }
+        } else if (m == 10) {
+            for (int i = 0; i < N; i++) {
+                int p = l[i];
+                if (edge && i == 0) p = hv_clip8(p + ((a[j] - c) >> 1));
+                pred[i * N + j] = (u8)p; scr[i * RS + j] = (short)((int)S.org[ty + i][ox] - p);
+            }
+        } else if (m == 26) {
+            for (int i = 0; i < N; i++) {
+                int p = a[j];
+                if (edge && j == 0) p = hv_clip8(p + ((l[i] - c) >> 1));
+                pred[i * N + j] = (u8)p; scr[i * RS + j] = (short)((int)S.org[ty + i][ox] - p);
+            }
+        } else {
+            /* angular: reference line r(k): k>0 main side, k==0 corner, k<0 side samples projected by the inverse angle */
+            const bool horiz = m < 18;
+            const int ang = hv_ang[m], inv = hv_invang[m];
+            const u8 *mainr = horiz ? l : a, *sider = horiz ? a : l;
+            for (int i = 0; i < N; i++) {
+                const int step = horiz ? j : i, along = horiz ? i : j;
+                const int off = ang * (step + 1), oi = off >> 5, of = off & 31;
+                int k1 = oi + along + 1, k2 = k1 + 1;
+                if (k2 > 2 * N) k2 = 2 * N;                 /* weight 0 there (modes 2 / 34): any in-range sample */
+                const int p1 = k1 > 0 ? mainr[k1 - 1] : (k1 == 0 ? c : sider[((128 - inv * k1) >> 8) - 1]);
+                const int p2 = k2 > 0 ? mainr[k2 - 1] : (k2 == 0 ? c : sider[((128 - inv * k2) >> 8) - 1]);
+                const int p = ((32 - of) * p1 + of * p2 + 16) >> 5;
+                pred[i * N + j] = (u8)p; scr[i * RS + j] = (short)((int)S.org[ty + i][ox] - p);
+            }
+        }
+    }
+
+    /* ---- forward transform, columns then rows  [ref HEVCe.c:497-516] ---- */
+    int v[N];
+    {
+        constexpr int s1 = LG - 1;
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = scr[k * RS + j];
+        const int *tab = HvTm<N>::f();
+        for (int i = 0; i < N; i++) {
+            int acc = 1 << s1 >> 1;
+#pragma unroll
+            for (int k = 0; k < N; k++) acc += hv_mul24(tab[i * N + k], v[k]);
+            scr[i * RS + j] = (short)(acc >> s1);
+        }
+    }
+    WAVE_SYNC();
+    /* ---- row pass + quantiser + dequantiser on row j  [ref HEVCe.c:540-615] ---- */
+    const int kind = hv_scan_kind(N, m);
+    int last = -1, nzmask_lo = 0, nzmask_hi = 0;
+    {
+        constexpr int s2 = LG - 1 + 7;
+        const int sh = 21 - LG + q, dsh = 10 - LG, thr = 9 << sh >> 2, qsh = 7 - LG + q;
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = scr[j * RS + k];
+        const int *tab = HvTm<N>::f();
+        for (int g = 0; g < N / 4; g++) {
+            int lv[4], sum = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int cidx = g * 4 + e;
+                int acc = 1 << s2 >> 1;
+#pragma unroll
+                for (int k = 0; k < N; k++) acc += hv_mul24(tab[cidx * N + k], v[k]);
+                const int coef = acc >> s2;
+                int d;
+                const int mag = hv_quant1(q, sh, dsh, hv_abs(coef), d);
+                lv[e] = coef < 0 ? -mag : mag;
+                sum += hv_min(d, thr);
+            }
+            sum += hv_shfl_xor(sum, 1);                       /* the 4x4 group spans rows j&~3 .. j|3 = 4 adjacent lanes */
+            sum += hv_shfl_xor(sum, 2);
+            int any = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (sum < thr) lv[e] = 0;
+                any |= lv[e];
+                const int x = g * 4 + e;
+                const int si = hv_scan_idx(S, LG, kind, j, x);
+                if (lv[e] && si > last) last = si;
+                if (mode >= 0) lev_dst[si] = (short)lv[e];
+                scr[j * RS + x] = (short)hv_clip16((int)((unsigned)lv[e] << qsh));
+            }
+            any = any != 0;
+            any |= hv_shfl_xor(any, 1);
+            any |= hv_shfl_xor(any, 2);
+            if (any) { const int bit = (j >> 2) * 8 + g; if (bit < 32) nzmask_lo |= 1 << bit; else nzmask_hi |= 1 << (bit - 32); }
+        }
+    }
+    for (int s = 1; s < N; s <<= 1) {
+        last = hv_max(last, hv_shfl_xor(last, s));
+        nzmask_lo |= hv_shfl_xor(nzmask_lo, s);
+        nzmask_hi |= hv_shfl_xor(nzmask_hi, s);
+    }
+    WAVE_SYNC();
+    /* ---- inverse transform, columns then rows ---- */
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = scr[k * RS + j];
+        const int *tab = HvTm<N>::t();
+        for (int i = 0; i < N; i++) {
+            int acc = 64;
+#pragma unroll
+            for (int k = 0; k < N; k++) acc += hv_mul24(tab[i * N + k], v[k]);
+            scr[i * RS + j] = (short)hv_clip16(acc >> 7);
+        }
+    }
+    WAVE_SYNC();
+    int sse = 0;
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = scr[j * RS + k];
+        const int *tab = HvTm<N>::t();
+        for (int x = 0; x < N; x++) {
+            int acc = 2048;
+#pragma unroll
+            for (int k = 0; k < N; k++) acc += hv_mul24(tab[x * N + k], v[k]);
+            const int r = hv_clip8(hv_clip16(acc >> 12) + pred[j * N + x]);
+            const int d = (int)S.org[ty + j][tx + x] - r;
+            sse += d * d;
+            if (mode >= 0) rec_dst[j * rec_stride + x] = (u8)r;
+        }
+    }
+    for (int s = 1; s < N; s <<= 1) sse += hv_shfl_xor(sse, s);
+    WAVE_SYNC();
+    HvTuOut o;
+    o.sse = sse; o.cbf = (last >= 0); o.last = last < 0 ? 0 : last;
+    o.cgsig = ((u64)(unsigned)nzmask_hi << 32) | (unsigned)nzmask_lo;
+    return o;
+}
+
+/* availability of the four z-ordered sub-blocks  [ref HEVCe.c:1376-1379] */
+static HD void hv_sub_avail(int s, int L, int LB, int A, int AR, int &l, int &lb, int &a, int &ar) {
+    l  = (s & 1) ? 1 : L;
+    lb = (s == 0) ? L : (s == 2 ? LB : 0);
+    a  = (s & 2) ? 1 : A;
+    ar = (s == 0) ? A : (s == 1 ? AR : (s == 2 ? 1 : 0));
+}
+
+struct HvCu { int y, x, n, lg, lvl, L, LB, A, AR; };         /* CTU-relative CU under evaluation; lvl = lg-3 */
+
+/* step 2 jobs: one TU of the CU size  [ref HEVCe.c:1422-1432] */
+template <int N>
+static HD void hv_job_single(HvLds &S, HvWaveScr &W, int lane, int q, const HvCu &cu, int grp, short *glev, u8 *grec) {
+    const int slot = lane / N, j = lane % N;
+    const int mode = grp * (64 / N) + slot;
+    const bool ok = mode < HEVCE_NMODES;
+    HvTuOut o = hv_tu_job<N>(S, W, lane, q, cu.y, cu.x, cu.y, cu.x, cu.n, nullptr, cu.L, cu.LB, cu.A, cu.AR,
+                             ok ? mode : -1, glev + (ok ? mode : 0) * 1024, grec + (ok ? mode : 0) * 1024, N);
+    if (ok && j == 0) {
+        S.tsse[mode] = o.sse;
+        S.tinfo[mode][0].cgsig = o.cgsig; S.tinfo[mode][0].last = o.last; S.tinfo[mode][0].cbf = o.cbf;
+    }
+}
+/* step 3 jobs: four TUs of half the CU size, each predicted from the previous ones' reconstruction  [ref :1455-1468] */
+template <int H>
+static HD void hv_job_chain(HvLds &S, HvWaveScr &W, int lane, int q, const HvCu &cu, int grp, short *glev, u8 *grec) {
+    const int slot = lane / H, j = lane % H, n = cu.n;
+    const int mode = grp * (64 / H) + slot;
+    const bool ok = mode < HEVCE_NMODES;
+    const int t = 35 + (ok ? mode : 0);
+    u8 *crec = W.crec + slot * n * n;
+    int total = 0;
+    for (int s = 0; s < 4; s++) {
+        int l, lb, a, ar;
+        hv_sub_avail(s, cu.L, cu.LB, cu.A, cu.AR, l, lb, a, ar);
+        const int oy = (s >> 1) * H, ox = (s & 1) * H;
+        HvTuOut o = hv_tu_job<H>(S, W, lane, q, cu.y + oy, cu.x + ox, cu.y, cu.x, n, crec, l, lb, a, ar,
+                                 ok ? mode : -1, glev + t * 1024 + s * H * H, crec + oy * n + ox, n);
+        total += o.sse;
+        if (ok && j == 0) { S.tinfo[t][s].cgsig = o.cgsig; S.tinfo[t][s].last = o.last; S.tinfo[t][s].cbf = o.cbf; }
+    }
+    if (ok) {
+        if (j == 0) S.tsse[t] = total;
+        for (int r = j; r < n; r += H)                      /* publish the whole CU reconstruction of this candidate */
+            for (int x = 0; x < n; x++) grec[t * 1024 + r * n + x] = crec[r * n + x];
+    }
+    WAVE_SYNC();
+}
+/* NxN job (8x8 CU only): per 4x4 sub-block choose the mode with a fresh coder and fresh contexts  [ref :1499-1528] */
+static HD void hv_job_nxn(HvLds &S, HvWaveScr &W, int lane, int q, const HvCu &cu) {
+    const int slot = lane >> 2, j = lane & 3;
+    int total = 0;
+    for (int s = 0; s < 4; s++) {
+        int l, lb, a, ar;
+        hv_sub_avail(s, cu.L, cu.LB, cu.A, cu.AR, l, lb, a, ar);
+        const int oy = (s >> 1) * 4, ox = (s & 1) * 4;
+        for (int g = 0; g < 3; g++) {
+            const int mode = g * 16 + slot;
+            const bool ok = mode < HEVCE_NMODES;
+            HvTuOut o = hv_tu_job<4>(S, W, lane, q, cu.y + oy, cu.x + ox, cu.y, cu.x, 8, &S.nxn_crec[0][0], l, lb, a, ar,
+                                     ok ? mode : -1, S.nxn_lev[ok ? mode : 0], S.nxn_rec[ok ? mode : 0], 4);
+            if (ok && j == 0) { S.nxn_sse[mode] = o.sse; S.nxn_last[mode] = o.last; S.nxn_sig[mode] = o.cbf; }
+        }
+        WAVE_SYNC();
+        /* rate of every candidate: lane = mode  [ref :1505-1519]; residual_coding is written even for an all-zero block */
+        int cost = HV_I32MAX, idx = -1;
+        if (lane < HEVCE_NMODES) {
+            u8 *cx = &S.tctx[0][lane];
+            for (int k = 0; k < 3; k++) { *HV_CX(CX_LASTX + k) = S.ctx_fresh[CX_LASTX + k]; *HV_CX(CX_LASTY + k) = S.ctx_fresh[CX_LASTY + k]; }
+            for (int k = 0; k < 9; k++) *HV_CX(CX_SIG + k) = S.ctx_fresh[CX_SIG + k];
+            for (int k = 0; k < 4; k++) *HV_CX(CX_ONE + k) = S.ctx_fresh[CX_ONE + k];
+            *HV_CX(CX_ABS) = S.ctx_fresh[CX_ABS];
+            HvCod c;
+            hv_cod_fresh(c);
+            hv_put_residual(S, c, cx, lane, 4, 2, lane, S.nxn_lev[lane], S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0));
+            cost = hv_rdcost(q, S.nxn_sse[lane], hv_cod_bits(c));
+            idx = lane;
+        }
+        for (int sft = 1; sft < 64; sft <<= 1) {             /* minimum cost, the LATER mode wins ties  [ref :1521] */
+            const int oc = hv_shfl_xor(cost, sft), oi = hv_shfl_xor(idx, sft);
+            if (oc < cost || (oc == cost && oi > idx)) { cost = oc; idx = oi; }
+        }
+        const int w = idx;
+        if (lane < 16) {
+            S.nxn_crec[oy + (lane >> 2)][ox + (lane & 3)] = S.nxn_rec[w][lane];
+            S.nxn_bestlev[s][lane] = S.nxn_lev[w][lane];
+        }
+        if (lane == 0) {
+            S.nxn_modes[s] = w;
+            S.tinfo[70][s].last = S.nxn_last[w]; S.tinfo[70][s].cbf = S.nxn_sig[w]; S.tinfo[70][s].cgsig = (u64)(S.nxn_sig[w] ? 1 : 0);
+        }
+        total += S.nxn_sse[w];
+        WAVE_SYNC();
+    }
+    if (lane == 0) S.tsse[70] = total;
+}
+/* distortion of the CU as currently reconstructed (the "split into four CUs" alternative)  [ref :1409] */
+static HD void hv_job_sse(HvLds &S, int lane, const HvCu &cu) {
+    int sse = 0;
+    for (int p = lane; p < cu.n * cu.n; p += 64) {
+        const int yy = cu.y + p / cu.n, xx = cu.x + p % cu.n;
+        const int d = (int)S.org[yy][xx] - S.rec[yy + 1][xx + HV_RX];
+        sse += d * d;
+    }
+    for (int s = 1; s < 64; s <<= 1) sse += hv_shfl_xor(sse, s);
+    if (lane == 0) S.split_sse = sse;
+}
+
+/* one context-coded bin on the committed coder (split_cu_flag = 1 of a parent)  [ref :1404] */
+static HD void hv_commit_bin(HvLds &S, int ctx, int bin) {
+    HvCod c;
+    hv_cod_load(c, S.com);
+    u8 tmp = S.com_ctx[ctx];
+    hv_bin(S, c, &tmp, bin);
+    S.com_ctx[ctx] = tmp;
+    hv_cod_store(S.com, c);
+}
+
+/* --------------------------------------------------------------------------------------------- */
+/* evaluation of one CU: TU jobs -> trial encodes -> arg-min -> commit   [ref HEVCe.c:1350-1560]    */
+/* --------------------------------------------------------------------------------------------- */
+static HD void hv_eval_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HevceRecord *rec) {
+    const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, n = cu.n;
+    short *glev = (short *)im.scratch;
+    u8 *grec = im.scratch + HV_TL * 1024 * 2;
+    const int ntrials = (n == 8) ? 71 : 70;
+    const int njobs = (n == 8) ? 9 : (n == 16) ? 15 : 28;
+
+    /* neighbour context, read at CU entry  [ref :1369-1373] */
+    const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
+    const int split_inc = (n > S.map_cu[my][mx - 1]) + (n > S.map_cu[my - 1][mx]);
+    const int ml = S.map_pm[my][mx - 1], ma = S.map_pm[my - 1][mx];
+
+    if (tid == 0) S.jobctr = 0;
+    for (int k = tid; k < 8 * 8; k += HV_NTHREADS) (&S.nxn_crec[0][0])[k] = 0;
+    BLOCK_SYNC();
+
+    /* ---------------- TU jobs, pulled from a queue (longest first) ---------------- */
+    for (;;) {
+        int job = 0;
+        if (lane == 0) job = hv_atomic_inc(&S.jobctr);
+        job = hv_bcast0(job);
+        if (job >= njobs) break;
+        HvWaveScr &W = S.ws[wave];
+        if (n == 8) {
+            if (job == 0) hv_job_nxn(S, W, lane, q, cu);
+            else if (job < 4) hv_job_chain<4>(S, W, lane, q, cu, job - 1, glev, grec);
+            else hv_job_single<8>(S, W, lane, q, cu, job - 4, glev, grec);
+        } else if (n == 16) {
+            if (job < 5) hv_job_chain<8>(S, W, lane, q, cu, job, glev, grec);
+            else if (job < 14) hv_job_single<16>(S, W, lane, q, cu, job - 5, glev, grec);
+            else hv_job_sse(S, lane, cu);
+        } else {
+            if (job < 9) hv_job_chain<16>(S, W, lane, q, cu, job, glev, grec);
+            else if (job < 27) hv_job_single<32>(S, W, lane, q, cu, job - 9, glev, grec);
+            else hv_job_sse(S, lane, cu);
+        }
+    }
+    BLOCK_SYNC();                                               /* the NxN job borrows trial context columns */
+    /* trial contexts start from the CU's entry snapshot  [ref :1423-1424] */
+    for (int k = tid; k < HEVCE_NCTXP * HV_TL; k += HV_NTHREADS) S.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[cu.lvl][k / HV_TL];
+    BLOCK_SYNC();
+
+    /* ---------------- trial encodes: lane = candidate  [ref :1434-1438, 1470-1474, 1540-1544] ---------------- */
+    {
+        const int t = lane * HV_NWAVES + wave;                  /* spread the candidates over all wavefronts */
+        if (lane < 9 && t < ntrials) {
+            HvCod c;
+            hv_cod_load(c, S.ent[cu.lvl]);
+            const int bits0 = hv_cod_bits(c);
+            u8 *cx = &S.tctx[0][t];
+            if (n >= 16) hv_bin(S, c, HV_CX(CX_SPLIT_CU + split_inc), 0);
+            if (t < 35) {
+                hv_put_cu(S, c, cx, t, n, cu.lg, 0, &t, &ml, &ma, glev + t * 1024, 0, S.tinfo[t]);
+            } else if (t < 70) {
+                const int m = t - 35;
+                hv_put_cu(S, c, cx, t, n, cu.lg, 1, &m, &ml, &ma, glev + t * 1024, (n >> 1) * (n >> 1), S.tinfo[t]);
+            } else {
+                int modes[4], lefts[4], aboves[4];
+                for (int s = 0; s < 4; s++) modes[s] = S.nxn_modes[s];
+                lefts[0] = ml;        aboves[0] = ma;                                   /* [ref :1531-1538] */
+                lefts[1] = modes[0];  aboves[1] = S.map_pm[my - 1][mx + 1];
+                lefts[2] = S.map_pm[my + 1][mx - 1];  aboves[2] = modes[0];
+                lefts[3] = modes[2];  aboves[3] = modes[1];
+                hv_put_cu(S, c, cx, t, 8, 3, 2, modes, lefts, aboves, &S.nxn_bestlev[0][0], 16, S.tinfo[70]);
+            }
+            S.tcost[t] = hv_rdcost(q, S.tsse[t], hv_cod_bits(c) - bits0);
+            hv_cod_store(S.tregs[t], c);
+        }
+    }
+    BLOCK_SYNC();
+
+    /* ---------------- arg-min in the reference's order, later candidate wins ties ---------------- */
+    if (tid == 0) {
+        int best = HV_I32MAX, w = -1;
+        if (n > 8) best = hv_rdcost(q, S.split_sse, hv_regs_bits(S.com) - hv_regs_bits(S.ent[cu.lvl]));
+        for (int t = 0; t < ntrials; t++) if (best >= S.tcost[t]) { best = S.tcost[t]; w = t; }
+        S.winner = w;
+    }
+    BLOCK_SYNC();
+    const int w = S.winner;
+    if (w < 0) return;                                          /* the four sub-CUs stay */
+
+    /* ---------------- commit the winner: coder, contexts, reconstruction, maps, record ---------------- */
+    if (tid == 0) S.com = S.tregs[w];
+    if (tid < HEVCE_NCTXP) S.com_ctx[tid] = S.tctx[tid][w];
+    const int kindw = w < 35 ? 0 : (w < 70 ? 1 : 2);
+    for (int p = tid; p < n * n; p += HV_NTHREADS) {
+        const int yy = p / n, xx = p % n;
+        S.rec[cu.y + yy + 1][cu.x + xx + HV_RX] = (kindw == 2) ? S.nxn_crec[yy][xx] : grec[w * 1024 + p];
+        int lv;
+        if (kindw == 0) {
+            lv = glev[w * 1024 + hv_scan_idx(S, cu.lg, hv_scan_kind(n, w), yy, xx)];
+        } else {
+            const int h = n >> 1, s = (yy >= h) * 2 + (xx >= h);
+            const int md = kindw == 1 ? w - 35 : S.nxn_modes[s];
+            const int si = hv_scan_idx(S, cu.lg - 1, hv_scan_kind(h, md), yy & (h - 1), xx & (h - 1));
+            lv = kindw == 1 ? glev[w * 1024 + s * h * h + si] : S.nxn_bestlev[s][si];
+        }
+        rec->lev[cu.y + yy][cu.x + xx] = (short)lv;
+    }
+    const int n4 = n >> 2;
+    if (tid < n4 * n4) {
+        const int i = tid / n4, jx = tid % n4;
+        const int md = kindw == 0 ? w : kindw == 1 ? w - 35 : S.nxn_modes[(i * 4 >= n / 2) * 2 + (jx * 4 >= n / 2)];
+        S.map_cu[my + i][mx + jx] = (u8)n;
+        S.map_pm[my + i][mx + jx] = (u8)md;
+        rec->mode[(cu.y >> 2) + i][(cu.x >> 2) + jx] = (u8)md;
+        rec->info[(cu.y >> 2) + i][(cu.x >> 2) + jx] = (u8)(cu.lvl | (kindw == 2 ? HEVCE_INFO_NXN : 0) | (kindw == 1 ? HEVCE_INFO_TUSPLIT : 0));
+    }
+    BLOCK_SYNC();
+}
+
+/* --------------------------------------------------------------------------------------------- */
+/* per-image driver: raster CTU loop  [ref HEVCe.c:1578-1647]                                       */
+/* --------------------------------------------------------------------------------------------- */
+static HD void hv_init_tables(HvLds &S, int q, int tid) {
+    if (tid < 64) { S.lps4[tid] = hv_lps4[tid]; S.lpsnext[tid] = hv_lpsnext[tid]; }
+    if (tid == 64) {
+        /* up-right diagonal order inside a 4x4 group and over 2x2 / 4x4 / 8x8 groups  [ref :1130-1132] */
+        int k = 0;
+        for (int d = 0; d <= 6; d++)
+            for (int y = (d < 4 ? d : 3); y >= 0 && d - y < 4; y--) { S.d4pos[k] = (u8)((y << 2) | (d - y)); S.d4idx[(y << 2) | (d - y)] = (u8)k; k++; }
+        for (int t = 0; t < 3; t++) {
+            const int ng = 2 << t;
+            k = 0;
+            for (int d = 0; d <= 2 * (ng - 1); d++)
+                for (int y = (d < ng ? d : ng - 1); y >= 0 && d - y < ng; y--) { S.cgpos[t][k] = (u8)((y << 3) | (d - y)); S.cgidx[t][y * ng + (d - y)] = (u8)k; k++; }
+        }
+    }
+    if (tid >= 128 && tid < 128 + HEVCE_NCTXP) {                                                          /* [ref :727-735] */
+        const int i = tid - 128, iv = hv_ctxinit[i], qp = 6 * q + 4;
+        int st = ((((iv >> 4) * 5 - 45) * qp) >> 4) + ((iv & 15) << 3) - 16;
+        st = hv_min(hv_max(st, 1), 126);
+        const u8 v = (u8)(st >= 64 ? (((st - 64) << 1) | 1) : ((63 - st) << 1));
+        S.ctx_fresh[i] = v; S.com_ctx[i] = v;
+    }
+    if (tid == 300) { S.com.range = 510; S.com.low = 0; S.com.nbits = 23; S.com.nbytes = 0; S.com.bufbyte = 0xff; S.com.zeros = 0; S.com.nout = 0; S.com.pad = 0; S.corner_next = 128; }
+}
+
+static HD void hv_snapshot(HvLds &S, int lvl, int tid) {
+    if (tid == 0) S.ent[lvl] = S.com;
+    if (tid < HEVCE_NCTXP) S.ent_ctx[lvl][tid] = S.com_ctx[tid];
+}
+
+static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
+    const int tid = hv_tid(), q = im.qpd6, H = im.H, W = im.W;
+    hv_init_tables(S, q, tid);
+    BLOCK_SYNC();
+    int ctu = 0;
+    for (int y0 = 0; y0 < H; y0 += 32) {
+        for (int x0 = 0; x0 < W; x0 += 32, ctu++) {
+            HevceRecord *rec = (HevceRecord *)(im.records + (size_t)ctu * HEVCE_REC_BYTES);
+            const int L = x0 > 0, A = y0 > 0, AR = A && (x0 + 32 < W);
+            /* ---- load the CTU: source samples (edge-replicated), neighbours, maps  [ref :1611-1622] ---- */
+            for (int p = tid; p < 1024; p += HV_NTHREADS) {
+                const int yy = hv_min(y0 + (p >> 5), im.src_h - 1), xx = hv_min(x0 + (p & 31), im.src_w - 1);
+                S.org[p >> 5][p & 31] = im.img[(size_t)yy * im.src_w + xx];
+            }
+            if (tid < 32) S.rec[1 + tid][HV_RX - 1] = L ? S.rec[1 + tid][HV_RX + 31] : 128;   /* left column = previous CTU's last column */
+            BLOCK_SYNC();
+            if (tid < 65) S.rec[0][HV_RX - 1 + tid] = (tid == 0) ? (u8)S.corner_next : S.line_rec[x0 + tid - 1];
+            if (tid >= 128 && tid < 136) {
+                const int i = tid - 128;
+                S.map_cu[1 + i][0] = L ? S.map_cu[1 + i][8] : 32;
+                S.map_pm[1 + i][0] = L ? S.map_pm[1 + i][8] : 1;
+            }
+            BLOCK_SYNC();
+            if (tid >= 192 && tid < 201) {
+                const int jx = tid - 192;                        /* row above: CU sizes of the CTU row above, modes always DC */
+                S.map_cu[0][jx] = (A && (jx > 0 || L)) ? S.line_cu[(x0 >> 2) + jx - 1] : 32;
+                if (jx == 0 && !A) S.map_cu[0][0] = 32;
+                S.map_pm[0][jx] = 1;
+            }
+            for (int p = tid; p < (int)(sizeof(HevceRecord) / 4); p += HV_NTHREADS) ((int *)rec)[p] = 0;
+            BLOCK_SYNC();
+
+            /* ---- quad-tree, depth first in z-order  [ref :1403-1407]: 21 CUs = 4 x (4 x 8x8, 16x16), 32x32 ---- */
+            const HvCu c32 = { 0, 0, 32, 5, 2, L, 0, A, AR };
+            for (int step = 0; step < 21; step++) {
+                const int k = step / 5, m = step % 5;
+                HvCu c16 = { (k >> 1) * 16, (k & 1) * 16, 16, 4, 1, 0, 0, 0, 0 };
+                hv_sub_avail(k & 3, c32.L, c32.LB, c32.A, c32.AR, c16.L, c16.LB, c16.A, c16.AR);
+                HvCu cu = c16;
+                if (step == 20) cu = c32;
+                else if (m < 4) {
+                    cu.y = c16.y + (m >> 1) * 8; cu.x = c16.x + (m & 1) * 8; cu.n = 8; cu.lg = 3; cu.lvl = 0;
+                    hv_sub_avail(m, c16.L, c16.LB, c16.A, c16.AR, cu.L, cu.LB, cu.A, cu.AR);
+                }
+                if (step == 0) {                                 /* entering the 32x32 CU: snapshot, then split_cu_flag = 1 */
+                    hv_snapshot(S, 2, tid);
+                    BLOCK_SYNC();
+                    if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + (32 > S.map_cu[1][0]) + (32 > S.map_cu[0][1]), 1);
+                    BLOCK_SYNC();
+                }
+                if (step < 20 && m == 0) {                       /* entering a 16x16 CU */
+                    hv_snapshot(S, 1, tid);
+                    BLOCK_SYNC();
+                    if (tid == 0) {
+                        const int my = 1 + (c16.y >> 2), mx = 1 + (c16.x >> 2);
+                        hv_commit_bin(S, CX_SPLIT_CU + (16 > S.map_cu[my][mx - 1]) + (16 > S.map_cu[my - 1][mx]), 1);
+                    }
+                    BLOCK_SYNC();
+                }
+                if (cu.n == 8) { hv_snapshot(S, 0, tid); BLOCK_SYNC(); }
+                hv_eval_cu(S, im, cu, rec);
+            }
+
+            /* ---- end of CTU: terminate bin, publish reconstruction and line buffers  [ref :1626-1637] ---- */
+            if (tid == 0) {
+                HvCod c;
+                hv_cod_load(c, S.com);
+                hv_terminate(c, (y0 + 32 >= H) && (x0 + 32 >= W));
+                hv_cod_store(S.com, c);
+                if (im.ctu_state) {
+                    int32_t *st = im.ctu_state + (size_t)ctu * 8;
+                    st[0] = c.range; st[1] = (int32_t)c.low; st[2] = c.nbits; st[3] = c.nbytes; st[4] = c.bufbyte; st[5] = c.zeros;
+                    st[6] = c.nout; st[7] = hv_cod_bits(c);
+                }
+                S.corner_next = S.line_rec[x0 + 31];
+            }
+            for (int p = tid; p < 1024; p += HV_NTHREADS)
+                im.rcon[(size_t)(y0 + (p >> 5)) * W + x0 + (p & 31)] = S.rec[1 + (p >> 5)][HV_RX + (p & 31)];
+            BLOCK_SYNC();
+            if (tid < 32) S.line_rec[x0 + tid] = S.rec[32][HV_RX + tid];
+            if (tid >= 64 && tid < 72) S.line_cu[(x0 >> 2) + tid - 64] = S.map_cu[8][1 + tid - 64];
+            BLOCK_SYNC();
+        }
+    }
+}

@@ -1,0 +1,1056 @@
+/*
+ * hevce_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE)
+ *
+ * A plain-C restatement of the hot path of lidongxuan/HEVC-image-encoder-lite
+ * (reference: src/HEVCe.c).  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this file's shared object; the product
+ * library (hevc-image-encoder-lite_amd/csrc) never links, includes or calls it.
+ *
+ * Parity status: PINNED.  The restatement is checked (oracle/validate_oracle.py,
+ * tests/test_oracle_*.py) against
+ *   - the reference's own goldens testimage_out/NN.h265 (qpd6=4, 24 images),
+ *   - the real reference compiled from /root/reference/src into oracle/_ref/
+ *     (all 24 Kodak images x qpd6 0..4, synthetic and odd-size images, and
+ *     function-level comparisons of prediction / transform / quantiser /
+ *     residual-coding rate).
+ *
+ * The structure is deliberately different from the reference: it is the CPU twin
+ * of the MI355X design:
+ *   analysis  : CU quad-tree RD search that carries a *counting* arithmetic coder
+ *               (registers + emulation-prevention tracking, no byte buffer) and
+ *               writes one fixed-size DECISION RECORD per CTU;
+ *   writer    : replays the records through a byte-emitting coder -> .h265.
+ * Tables are generated (DCT basis from its 33 distinct magnitudes, scans from
+ * the diagonal rule) instead of being spelled out.
+ *
+ * Each function cites the reference lines it restates as  [ref HEVCe.c:a-b].
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* constants                                                                 */
+/* ------------------------------------------------------------------------- */
+enum { CTU = 32, MAXDIM = 8192, NMODES = 35, M_PLANAR = 0, M_DC = 1, M_HOR = 10, M_VER = 26 };
+#define I32MAX 0x7fffffff
+
+/* compact context layout (only the contexts a luma-only stream touches) */
+enum {
+    CX_SPLIT_CU = 0,   /* 3 */
+    CX_PART     = 3,
+    CX_YPM      = 4,
+    CX_UVPM     = 5,
+    CX_SPLIT_TU = 6,   /* 3 : 32,16,8 */
+    CX_YCBF     = 9,   /* 2 : index = (depth==0) */
+    CX_UVCBF    = 11,  /* 1 */
+    CX_LASTX    = 12,  /* 4 size classes x 5 */
+    CX_LASTY    = 32,
+    CX_SIGCG    = 52,  /* 2 */
+    CX_SIG      = 54,  /* 27 (+1 pad) */
+    CX_ONE      = 82,  /* 16 */
+    CX_ABS      = 98,  /* 4 */
+    NCTX        = 102
+};
+
+/* H.265 9.3.2.2 initValue, I slices  [ref HEVCe.c:763-777 uses the same numbers] */
+static const uint8_t CTX_INITVAL[NCTX] = {
+    139, 141, 157,                                   /* split_cu_flag            */
+    184,                                             /* part_mode                */
+    184,                                             /* prev_intra_luma_pred     */
+    63,                                              /* intra_chroma_pred_mode   */
+    153, 138, 138,                                   /* split_transform_flag     */
+    111, 141,                                        /* cbf_luma                 */
+    94,                                              /* cbf_cb / cbf_cr, depth 0 */
+    110, 110, 124, 0, 0,  125, 140, 153, 0, 0,       /* last_x prefix 4x4, 8x8   */
+    125, 127, 140, 109, 0,  111, 143, 127, 111, 79,  /* last_x prefix 16, 32     */
+    110, 110, 124, 0, 0,  125, 140, 153, 0, 0,       /* last_y                   */
+    125, 127, 140, 109, 0,  111, 143, 127, 111, 79,
+    91, 171,                                         /* coded_sub_block_flag     */
+    111, 111, 125, 110, 110, 94, 124, 108, 124,      /* sig_coeff_flag (luma)    */
+    107, 125, 141, 179, 153, 125, 107, 125, 141,
+    179, 153, 125, 107, 125, 141, 179, 153, 125, 0,
+    140, 92, 137, 138, 140, 152, 138, 139,           /* greater1 (luma)          */
+    153, 74, 149, 92, 139, 107, 122, 152,
+    138, 153, 136, 167                               /* greater2 (luma)          */
+};
+
+/* H.265 table 9-46 rangeTabLps */
+static const uint8_t LPS_RANGE[64][4] = {
+    {128,176,208,240},{128,167,197,227},{128,158,187,216},{123,150,178,205},{116,142,169,195},{111,135,160,185},
+    {105,128,152,175},{100,122,144,166},{ 95,116,137,158},{ 90,110,130,150},{ 85,104,123,142},{ 81, 99,117,135},
+    { 77, 94,111,128},{ 73, 89,105,122},{ 69, 85,100,116},{ 66, 80, 95,110},{ 62, 76, 90,104},{ 59, 72, 86, 99},
+    { 56, 69, 81, 94},{ 53, 65, 77, 89},{ 51, 62, 73, 85},{ 48, 59, 69, 80},{ 46, 56, 66, 76},{ 43, 53, 63, 72},
+    { 41, 50, 59, 69},{ 39, 48, 56, 65},{ 37, 45, 54, 62},{ 35, 43, 51, 59},{ 33, 41, 48, 56},{ 32, 39, 46, 53},
+    { 30, 37, 43, 50},{ 29, 35, 41, 48},{ 27, 33, 39, 45},{ 26, 31, 37, 43},{ 24, 30, 35, 41},{ 23, 28, 33, 39},
+    { 22, 27, 32, 37},{ 21, 26, 30, 35},{ 20, 24, 29, 33},{ 19, 23, 27, 31},{ 18, 22, 26, 30},{ 17, 21, 25, 28},
+    { 16, 20, 23, 27},{ 15, 19, 22, 25},{ 14, 18, 21, 24},{ 14, 17, 20, 23},{ 13, 16, 19, 22},{ 12, 15, 18, 21},
+    { 12, 14, 17, 20},{ 11, 14, 16, 19},{ 11, 13, 15, 18},{ 10, 12, 15, 17},{ 10, 12, 14, 16},{  9, 11, 13, 15},
+    {  9, 11, 12, 14},{  8, 10, 12, 14},{  8,  9, 11, 13},{  7,  9, 11, 12},{  7,  9, 10, 12},{  7,  8, 10, 11},
+    {  6,  8,  9, 11},{  6,  7,  9, 10},{  6,  7,  8,  9},{  2,  2,  2,  2}
+};
+/* H.265 table 9-47 transIdxLps */
+static const uint8_t LPS_NEXT[64] = {
+     0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9,11,11,12,13,13,15,15,16,16,18,18,19,19,21,21,22,22,23,24,
+    24,25,26,26,27,27,28,29,29,30,30,30,31,32,32,33,33,33,34,34,35,35,35,36,36,36,37,37,37,38,38,63
+};
+
+/* ------------------------------------------------------------------------- */
+/* generated tables                                                          */
+/* ------------------------------------------------------------------------- */
+static int16_t  T32[32][32], T16[16][16], T8[8][8];
+static const int16_t T4[4][4] = { {29,55,74,84}, {74,74,0,-74}, {84,-29,-74,55}, {55,-84,74,-29} };  /* DST-VII */
+static uint8_t  SCAN_D4[16][2], SCAN_D8[64][2], SCAN_D16[256][2], SCAN_D32[1024][2], SCAN_H8[64][2], SCAN_V8[64][2];
+static int      tables_ready = 0;
+
+/* the 33 magnitudes of the HEVC core transform, index m <-> cos(m*pi/64)  [ref HEVCe.c:431-464] */
+static const int8_t COSMAG[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                                   61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+static int basis(int k, int n) {           /* DCT-II entry k,n of the 32-point matrix */
+    int m;
+    if (k == 0) return 64;
+    m = (k * (2 * n + 1)) & 127;
+    if (m > 64) m = 128 - m;
+    return (m > 32) ? -COSMAG[64 - m] : COSMAG[m];
+}
+
+static void diag_scan(int n, uint8_t (*out)[2]) {          /* [ref HEVCe.c:1130-1132] */
+    /* up-right diagonal over 4x4 groups, and up-right diagonal inside each group */
+    int ng = n / 4, gd, gy, d, y, k = 0;
+    for (gd = 0; gd <= 2 * (ng - 1); gd++)
+        for (gy = (gd < ng ? gd : ng - 1); gy >= 0 && gd - gy < ng; gy--) {
+            int gx = gd - gy;
+            for (d = 0; d <= 6; d++)
+                for (y = (d < 4 ? d : 3); y >= 0 && d - y < 4; y--) {
+                    out[k][0] = (uint8_t)(gy * 4 + y);
+                    out[k][1] = (uint8_t)(gx * 4 + d - y);
+                    k++;
+                }
+        }
+}
+
+static void build_tables(void) {
+    int k, n, g, i;
+    if (tables_ready) return;
+    for (k = 0; k < 32; k++) for (n = 0; n < 32; n++) T32[k][n] = (int16_t)basis(k, n);
+    for (k = 0; k < 16; k++) for (n = 0; n < 16; n++) T16[k][n] = T32[2 * k][n];
+    for (k = 0; k < 8;  k++) for (n = 0; n < 8;  n++) T8[k][n]  = T32[4 * k][n];
+    diag_scan(4, SCAN_D4); diag_scan(8, SCAN_D8); diag_scan(16, SCAN_D16); diag_scan(32, SCAN_D32);
+    for (g = 0; g < 4; g++)                                 /* [ref HEVCe.c:1128-1129] */
+        for (i = 0; i < 16; i++) {
+            /* horizontal: groups row-major, raster inside; vertical: groups column-major, columns inside */
+            SCAN_H8[g * 16 + i][0] = (uint8_t)((g >> 1) * 4 + (i >> 2));
+            SCAN_H8[g * 16 + i][1] = (uint8_t)((g & 1) * 4 + (i & 3));
+            SCAN_V8[g * 16 + i][0] = (uint8_t)((g & 1) * 4 + (i & 3));
+            SCAN_V8[g * 16 + i][1] = (uint8_t)((g >> 1) * 4 + (i >> 2));
+        }
+    tables_ready = 1;
+}
+
+static inline int iabs(int v) { return v < 0 ? -v : v; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int clip16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+static inline int clip8(int v)  { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+static inline int log2i(int n)  { return n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5; }
+
+/* ------------------------------------------------------------------------- */
+/* RD cost  [ref HEVCe.c:177-185]                                            */
+/* ------------------------------------------------------------------------- */
+static const int W_DIST[5] = { 11, 11, 11, 5, 1 };
+static const int W_BITS[5] = { 1, 4, 16, 29, 23 };
+static int rd_cost(int q, int dist, int bits) {
+    int a = (I32MAX / W_DIST[q] <= dist) ? I32MAX : W_DIST[q] * dist;
+    int b = (I32MAX / W_BITS[q] <= bits) ? I32MAX : W_BITS[q] * bits;
+    return (I32MAX - a <= b) ? I32MAX : a + b;
+}
+
+/* ------------------------------------------------------------------------- */
+/* intra reference samples + prediction                                       */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    uint8_t c[2];          /* corner: [0] raw, [1] smoothed          */
+    uint8_t l[2][64];      /* left + left-below, raw / smoothed      */
+    uint8_t a[2][64];      /* above + above-right, raw / smoothed    */
+} Refs;
+
+/* [ref HEVCe.c:196-257]  rec points at the block's top-left sample inside a picture of stride rs */
+static void fetch_refs(Refs *R, int n, const uint8_t *rec, int rs, int hasL, int hasLB, int hasA, int hasAR) {
+    int i;
+    uint8_t *l = R->l[0], *a = R->a[0];
+    if (hasL && hasA)   R->c[0] = rec[-rs - 1];
+    else if (hasL)      R->c[0] = rec[-1];
+    else if (hasA)      R->c[0] = rec[-rs];
+    else                R->c[0] = 128;
+    for (i = 0; i < n; i++)      l[i] = hasL  ? rec[i * rs - 1] : R->c[0];
+    for (i = n; i < 2 * n; i++)  l[i] = hasLB ? rec[i * rs - 1] : l[n - 1];
+    for (i = 0; i < n; i++)      a[i] = hasA  ? rec[-rs + i] : R->c[0];
+    for (i = n; i < 2 * n; i++)  a[i] = hasAR ? rec[-rs + i] : a[n - 1];
+    /* [1 2 1]/4 smoothing; the far ends are copied */
+    R->c[1]    = (uint8_t)((2 + l[0] + a[0] + 2 * R->c[0]) >> 2);
+    R->l[1][0] = (uint8_t)((2 + 2 * l[0] + l[1] + R->c[0]) >> 2);
+    R->a[1][0] = (uint8_t)((2 + 2 * a[0] + a[1] + R->c[0]) >> 2);
+    for (i = 1; i < 2 * n - 1; i++) {
+        R->l[1][i] = (uint8_t)((2 + 2 * l[i] + l[i - 1] + l[i + 1]) >> 2);
+        R->a[1][i] = (uint8_t)((2 + 2 * a[i] + a[i - 1] + a[i + 1]) >> 2);
+    }
+    R->l[1][2 * n - 1] = l[2 * n - 1];
+    R->a[1][2 * n - 1] = a[2 * n - 1];
+}
+
+/* which (size, mode) pairs read the smoothed references  [ref HEVCe.c:274-280]:
+   4x4 never; 8x8: planar, 2, 18, 34; 16x16: all but DC and |m-10|<=1, |m-26|<=1; 32x32: all but DC, 10, 26 */
+static int uses_smoothed(int n, int m) {
+    int dh, dv, d;
+    if (n == 4 || m == M_DC) return 0;
+    if (m == M_PLANAR) return 1;
+    dh = iabs(m - M_HOR); dv = iabs(m - M_VER); d = imin(dh, dv);
+    if (n == 8)  return d > 7;
+    if (n == 16) return d > 1;
+    return d > 0;
+}
+
+static const int8_t  ANG[35]   = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
+                                   -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+static const int16_t INVANG[35] = { 0, 0, 256, 315, 390, 482, 630, 910, 1638, 4096, 0, 4096, 1638, 910, 630, 482,
+                                    390, 315, 256, 315, 390, 482, 630, 910, 1638, 4096, 0, 4096, 1638, 910, 630,
+                                    482, 390, 315, 256 };
+
+/* [ref HEVCe.c:262-381]  luma only; out stride = n */
+static void predict_block(int n, int m, const Refs *R, uint8_t *out) {
+    const int f = uses_smoothed(n, m);
+    const int edge = (n <= 16);
+    const int c = R->c[f];
+    const uint8_t *l = R->l[f], *a = R->a[f];
+    int i, j;
+    if (m == M_PLANAR) {
+        for (i = 0; i < n; i++)
+            for (j = 0; j < n; j++)
+                out[i * n + j] = (uint8_t)((n + (n - 1 - j) * l[i] + (j + 1) * a[n] + (n - 1 - i) * a[j] + (i + 1) * l[n]) / (2 * n));
+    } else if (m == M_DC) {
+        int dc = n;
+        for (i = 0; i < n; i++) dc += l[i] + a[i];
+        dc /= 2 * n;
+        for (i = 0; i < n * n; i++) out[i] = (uint8_t)dc;
+        if (edge) {
+            out[0] = (uint8_t)((2 + 2 * dc + l[0] + a[0]) >> 2);
+            for (i = 1; i < n; i++) {
+                out[i]     = (uint8_t)((2 + 3 * dc + a[i]) >> 2);
+                out[i * n] = (uint8_t)((2 + 3 * dc + l[i]) >> 2);
+            }
+        }
+    } else if (m == M_HOR) {
+        for (i = 0; i < n; i++) for (j = 0; j < n; j++) out[i * n + j] = l[i];
+        if (edge) for (j = 0; j < n; j++) out[j] = (uint8_t)clip8(l[0] + ((a[j] - c) >> 1));
+    } else if (m == M_VER) {
+        for (i = 0; i < n; i++) for (j = 0; j < n; j++) out[i * n + j] = a[j];
+        if (edge) for (i = 0; i < n; i++) out[i * n] = (uint8_t)clip8(a[0] + ((l[i] - c) >> 1));
+    } else {
+        /* angular: 1-D reference line r[-n..2n], r[0] = corner, r[1..] = main side,
+           negative part = side reference projected through the inverse angle */
+        const int horiz = m < 18;
+        const int ang = ANG[m], inv = INVANG[m];
+        const uint8_t *mainr = horiz ? l : a, *sider = horiz ? a : l;
+        uint8_t line[3 * 64 + 2], *r = line + 64;
+        int k, lo = (n * ang) >> 5;
+        memset(line, 0, sizeof line);   /* r[2n+1] is read with weight 0 by modes 2 and 34 */
+        r[0] = (uint8_t)c;
+        for (k = 1; k <= 2 * n; k++) r[k] = mainr[k - 1];
+        for (k = -1; k > lo; k--) r[k] = sider[((128 - inv * k) >> 8) - 1];
+        for (i = 0; i < n; i++) {
+            int off = ang * (i + 1), oi = off >> 5, of = off & 31;
+            for (j = 0; j < n; j++) {
+                int v = ((32 - of) * r[oi + j + 1] + of * r[oi + j + 2] + 16) >> 5;
+                if (horiz) out[j * n + i] = (uint8_t)v; else out[i * n + j] = (uint8_t)v;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* transforms  [ref HEVCe.c:469-516]                                          */
+/* ------------------------------------------------------------------------- */
+static const int16_t *tmat(int n) {
+    return n == 4 ? &T4[0][0] : n == 8 ? &T8[0][0] : n == 16 ? &T16[0][0] : &T32[0][0];
+}
+/* forward: columns first, Y = ((C X + r1) >> s1) C^T, second rounding with s1+7; no clipping */
+static void fwd_transform(int n, const int *x, int *y) {
+    int tmp[32 * 32], acc[32];
+    const int16_t *c = tmat(n);
+    const int s1 = log2i(n) - 1, s2 = s1 + 7;
+    int i, j, k;
+    for (i = 0; i < n; i++) {
+        for (j = 0; j < n; j++) acc[j] = 1 << s1 >> 1;
+        for (k = 0; k < n; k++) { const int ck = c[i * n + k]; for (j = 0; j < n; j++) acc[j] += ck * x[k * n + j]; }
+        for (j = 0; j < n; j++) tmp[i * n + j] = acc[j] >> s1;
+    }
+    for (i = 0; i < n; i++)
+        for (j = 0; j < n; j++) {
+            int s = 1 << s2 >> 1;
+            for (k = 0; k < n; k++) s += tmp[i * n + k] * c[j * n + k];
+            y[i * n + j] = s >> s2;
+        }
+}
+/* inverse: X = clip16((C^T Y + 64) >> 7), then clip16((X C + 2048) >> 12) */
+static void inv_transform(int n, const int *y, int *x) {
+    int tmp[32 * 32], acc[32];
+    const int16_t *c = tmat(n);
+    int i, j, k;
+    for (i = 0; i < n; i++) {
+        for (j = 0; j < n; j++) acc[j] = 64;
+        for (k = 0; k < n; k++) { const int ck = c[k * n + i]; for (j = 0; j < n; j++) acc[j] += ck * y[k * n + j]; }
+        for (j = 0; j < n; j++) tmp[i * n + j] = clip16(acc[j] >> 7);
+    }
+    for (i = 0; i < n; i++) {
+        for (j = 0; j < n; j++) acc[j] = 2048;
+        for (k = 0; k < n; k++) { const int tk = tmp[i * n + k]; for (j = 0; j < n; j++) acc[j] += tk * c[k * n + j]; }
+        for (j = 0; j < n; j++) x[i * n + j] = clip16(acc[j] >> 12);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* quantiser (simplified RDOQ) + dequantiser  [ref HEVCe.c:526-615]           */
+/* ------------------------------------------------------------------------- */
+static int level_rate(int lv) {                       /* [ref HEVCe.c:526-535] */
+    static const int small[6] = { 0, 70000, 90000, 92000, 157536, 190304 };
+    int i;
+    if (lv < 6) return small[lv];
+    lv -= 6;
+    for (i = 0; (1 << i) <= lv; i++) lv -= 1 << i;
+    return 92000 + ((4 + 2 * i) << 15);
+}
+static void quantize_block(int q, int n, const int *coef, int *lev) {
+    const int lg = log2i(n);
+    const int dsh = 10 - lg;              /* 8,7,6,5 */
+    const int sh = 21 - lg + q;           /* 19,18,17,16 (+q) */
+    const int half = 1 << sh >> 1;
+    const int dmax = I32MAX - half;
+    const int thr = 9 << sh >> 2;
+    int gy, gx, y, x;
+    for (gy = 0; gy < n; gy += 4)
+        for (gx = 0; gx < n; gx += 4) {
+            int sum = 0;
+            for (y = gy; y < gy + 4; y++)
+                for (x = gx; x < gx + 4; x++) {
+                    int v = coef[y * n + x], av = iabs(v);
+                    int d = (av > 0x1ffff) ? dmax : imin((av & 0x1ffff) << 14, dmax);
+                    int lv = clip16((d + half) >> sh);
+                    int lo = imax(0, lv - 2), best = I32MAX, pick = 0;   /* pick is always assigned: see DESIGN.md */
+                    for (; lv >= lo; lv--) {
+                        int e = iabs(d - (lv << sh)) >> dsh;
+                        int dist = ((e < 46340) ? e * e : I32MAX) >> 7;
+                        int cst = rd_cost(q, dist, level_rate(lv));
+                        if (cst < best) { best = cst; pick = lv; }
+                    }
+                    lev[y * n + x] = v < 0 ? -pick : pick;
+                    sum += imin(d, thr);
+                }
+            if (sum < thr)
+                for (y = gy; y < gy + 4; y++) for (x = gx; x < gx + 4; x++) lev[y * n + x] = 0;
+        }
+}
+static void dequantize_block(int q, int n, const int *lev, int *coef) {
+    const int sh = 7 - log2i(n) + q;     /* 5,4,3,2 (+q) */
+    int i;
+    for (i = 0; i < n * n; i++) coef[i] = clip16((int)((unsigned)lev[i] << sh));
+}
+
+/* one TU trial: predict -> residual -> T -> Q -> Q^-1 -> T^-1 -> reconstruct; returns SSE
+   [ref HEVCe.c:1426-1437]  org/rec_out are n x n with strides os / n */
+static int tu_trial(int q, int n, int m, const Refs *R, const uint8_t *org, int os, int *lev, uint8_t *rec_out) {
+    uint8_t pred[32 * 32];
+    int a[32 * 32], b[32 * 32];
+    int i, j, sse = 0;
+    predict_block(n, m, R, pred);
+    for (i = 0; i < n; i++) for (j = 0; j < n; j++) a[i * n + j] = (int)org[i * os + j] - pred[i * n + j];
+    fwd_transform(n, a, b);
+    quantize_block(q, n, b, lev);
+    dequantize_block(q, n, lev, a);
+    inv_transform(n, a, b);
+    for (i = 0; i < n; i++)
+        for (j = 0; j < n; j++) {
+            int r = clip8(b[i * n + j] + pred[i * n + j]), d = (int)org[i * os + j] - r;
+            rec_out[i * n + j] = (uint8_t)r;
+            sse += d * d;
+        }
+    return sse;
+}
+
+/* ------------------------------------------------------------------------- */
+/* arithmetic coder  [ref HEVCe.c:797-933]                                    */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t  range, nbits, nbytes, bufbyte, zeros;
+    uint32_t low;
+    int64_t  nout;        /* bytes emitted so far, emulation-prevention bytes included */
+    uint8_t *sink;        /* NULL = counting coder (trials, analysis); else bytes are stored */
+} Coder;
+typedef struct { uint8_t s[NCTX]; } Ctxs;
+
+static void coder_init(Coder *c, uint8_t *sink) {     /* [ref HEVCe.c:809-812] */
+    c->range = 510; c->low = 0; c->nbits = 23; c->nbytes = 0; c->bufbyte = 0xff; c->zeros = 0; c->nout = 0; c->sink = sink;
+}
+static void ctxs_init(Ctxs *x, int q) {               /* [ref HEVCe.c:727-735, 762-785] */
+    int i, qp = 6 * q + 4;
+    for (i = 0; i < NCTX; i++) {
+        int iv = CTX_INITVAL[i];
+        int st = ((((iv >> 4) * 5 - 45) * qp) >> 4) + ((iv & 15) << 3) - 16;
+        st = st < 1 ? 1 : (st > 126 ? 126 : st);
+        x->s[i] = (uint8_t)(st >= 64 ? (((st - 64) << 1) | 1) : ((63 - st) << 1));
+    }
+}
+static inline int64_t coder_bits(const Coder *c) {    /* [ref HEVCe.c:835-837] */
+    return 8 * (c->nout + c->nbytes) + 23 - c->nbits;
+}
+static void coder_out(Coder *c, int byte) {           /* [ref HEVCe.c:821-832] start-code emulation prevention */
+    byte &= 0xff;
+    if (c->zeros >= 2 && byte <= 3) {
+        if (c->sink) c->sink[c->nout] = 3;
+        c->nout++; c->zeros = 0;
+    }
+    if (c->sink) c->sink[c->nout] = (uint8_t)byte;
+    c->nout++;
+    c->zeros = byte ? 0 : c->zeros + 1;
+}
+static void coder_carry(Coder *c) {                   /* [ref HEVCe.c:859-879] */
+    if (c->nbits < 12) {
+        int lead = (int)(c->low >> (24 - c->nbits));
+        c->nbits += 8;
+        c->low &= 0xffffffffu >> c->nbits;
+        if (lead == 0xff) {
+            c->nbytes++;
+        } else if (c->nbytes > 0) {
+            int carry = lead >> 8, fill = (0xff + carry) & 0xff;
+            coder_out(c, c->bufbyte + carry);
+            c->bufbyte = lead & 0xff;
+            for (; c->nbytes > 1; c->nbytes--) coder_out(c, fill);
+        } else {
+            c->nbytes = 1; c->bufbyte = lead;
+        }
+    }
+}
+static void enc_bin(Coder *c, uint8_t *cx, int bin) { /* [ref HEVCe.c:914-933] */
+    int st = *cx >> 1, mps = *cx & 1;
+    int lps = LPS_RANGE[st][(c->range >> 6) & 3];
+    c->range -= lps;
+    if ((bin != 0) != mps) {
+        int sh = __builtin_clz((unsigned)(lps >> 3) | 1u) - 26 + ((lps >> 3) == 0);   /* renorm count 6..1 */
+        *cx = (uint8_t)(st == 0 ? (mps ^ 1) : ((LPS_NEXT[st] << 1) | mps));
+        c->low = (c->low + (uint32_t)c->range) << sh;
+        c->range = lps << sh;
+        c->nbits -= sh;
+    } else {
+        if (st < 62) *cx = (uint8_t)(*cx + 2);
+        if (c->range < 256) { c->low <<= 1; c->range <<= 1; c->nbits--; }
+    }
+    coder_carry(c);
+}
+static void enc_bypass(Coder *c, int bins, int len) { /* [ref HEVCe.c:899-911] chunks of <= 8 */
+    bins &= (1 << len) - 1;
+    while (len > 0) {
+        int n = imin(len, 8);
+        len -= n;
+        c->low = (c->low << n) + (uint32_t)c->range * (uint32_t)((bins >> len) & ((1 << n) - 1));
+        c->nbits -= n;
+        coder_carry(c);
+    }
+}
+static void enc_terminate(Coder *c, int bin) {        /* [ref HEVCe.c:882-896] */
+    c->range -= 2;
+    if (bin) { c->low = (c->low + (uint32_t)c->range) << 7; c->range = 256; c->nbits -= 7; }
+    else if (c->range < 256) { c->low <<= 1; c->range <<= 1; c->nbits--; }
+    coder_carry(c);
+}
+static void coder_finish(Coder *c) {                  /* [ref HEVCe.c:840-856] */
+    int fill = 0, tail;
+    if ((c->low >> (32 - c->nbits)) > 0) {
+        coder_out(c, c->bufbyte + 1);
+        c->low -= 1u << (32 - c->nbits);
+    } else {
+        if (c->nbytes > 0) coder_out(c, c->bufbyte);
+        fill = 0xff;
+    }
+    for (; c->nbytes > 1; c->nbytes--) coder_out(c, fill);
+    tail = (int)((c->low >> 8) << c->nbits);
+    coder_out(c, tail >> 16); coder_out(c, tail >> 8); coder_out(c, tail);
+}
+
+/* ------------------------------------------------------------------------- */
+/* syntax                                                                     */
+/* ------------------------------------------------------------------------- */
+static void mpm_list(int left, int above, int out[3]) {       /* [ref HEVCe.c:958-977] */
+    if (left != above) {
+        out[0] = left; out[1] = above;
+        out[2] = (left != M_PLANAR && above != M_PLANAR) ? M_PLANAR : (left + above < 2 ? M_VER : M_DC);
+    } else if (left > M_DC) {
+        out[0] = left; out[1] = ((left + 29) % 32) + 2; out[2] = ((left - 1) % 32) + 2;
+    } else {
+        out[0] = M_PLANAR; out[1] = M_DC; out[2] = M_VER;
+    }
+}
+/* all prev_intra_luma_pred_flags first, then mpm_idx / rem_intra_luma_pred_mode  [ref HEVCe.c:985-1018] */
+static void put_luma_modes(Coder *c, Ctxs *x, int parts, const int *mode, const int *left, const int *above) {
+    int cand[4][3], hit[4], i, j;
+    for (i = 0; i < parts; i++) {
+        mpm_list(left[i], above[i], cand[i]);
+        hit[i] = -1;
+        for (j = 0; j < 3; j++) if (cand[i][j] == mode[i]) hit[i] = j;
+        enc_bin(c, &x->s[CX_YPM], hit[i] >= 0);
+    }
+    for (i = 0; i < parts; i++) {
+        if (hit[i] >= 0) {
+            enc_bypass(c, hit[i] > 0, 1);
+            if (hit[i] > 0) enc_bypass(c, hit[i] - 1, 1);
+        } else {
+            int rem = mode[i], t;
+            int *p = cand[i];
+            if (p[0] < p[1]) { t = p[0]; p[0] = p[1]; p[1] = t; }   /* sort descending */
+            if (p[1] < p[2]) { t = p[1]; p[1] = p[2]; p[2] = t; }
+            if (p[0] < p[1]) { t = p[0]; p[0] = p[1]; p[1] = t; }
+            for (j = 0; j < 3; j++) if (rem > p[j]) rem--;
+            enc_bypass(c, rem, 5);
+        }
+    }
+}
+
+static void put_last_pos(Coder *c, Ctxs *x, int n, int swap, int y, int xx) {   /* [ref HEVCe.c:1046-1087] */
+    static const uint8_t grp[32] = { 0,1,2,3,4,4,5,5,6,6,6,6,7,7,7,7,8,8,8,8,8,8,8,8,9,9,9,9,9,9,9,9 };
+    static const uint8_t gmin[10] = { 0, 1, 2, 3, 4, 6, 8, 12, 16, 24 };
+    const int cls = log2i(n) - 2, sh = (n == 4) ? 0 : 1;
+    int ty = swap ? xx : y, tx = swap ? y : xx;
+    int gy = grp[ty], gx = grp[tx], gmax = grp[n - 1], i;
+    for (i = 0; i < gx; i++) enc_bin(c, &x->s[CX_LASTX + 5 * cls + (i >> sh)], 1);
+    if (gx < gmax)           enc_bin(c, &x->s[CX_LASTX + 5 * cls + (gx >> sh)], 0);
+    for (i = 0; i < gy; i++) enc_bin(c, &x->s[CX_LASTY + 5 * cls + (i >> sh)], 1);
+    if (gy < gmax)           enc_bin(c, &x->s[CX_LASTY + 5 * cls + (gy >> sh)], 0);
+    if (gx > 3) { tx -= gmin[gx]; for (i = ((gx - 2) >> 1) - 1; i >= 0; i--) enc_bypass(c, (tx >> i) & 1, 1); }
+    if (gy > 3) { ty -= gmin[gy]; for (i = ((gy - 2) >> 1) - 1; i >= 0; i--) enc_bypass(c, (ty >> i) & 1, 1); }
+}
+
+static int sig_ctx_index(int n, int scan_is_diag, int y, int x, int nb) {       /* [ref HEVCe.c:1092-1122] luma */
+    static const uint8_t map4[4][4] = { {0,1,4,5}, {2,3,4,5}, {6,6,8,8}, {7,7,8,8} };
+    static const uint8_t pos[7] = { 2, 1, 1, 0, 0, 0, 0 };
+    int base = 9;
+    if (y == 0 && x == 0) return 0;
+    if (n == 4) return map4[y][x];
+    if (n >= 16) base += 12;
+    if (n == 8 && !scan_is_diag) base += 6;
+    if ((y >> 2) | (x >> 2)) base += 3;
+    switch (nb) {
+        case 0:  return base + pos[(y & 3) + (x & 3)];
+        case 1:  return base + pos[(y & 3) << 1];
+        case 2:  return base + pos[(x & 3) << 1];
+        default: return base + 2;
+    }
+}
+
+static void put_remainder(Coder *c, int v, int k) {            /* [ref HEVCe.c:1154-1169] */
+    if (v < (3 << k)) {
+        int pre = v >> k;
+        enc_bypass(c, (1 << (pre + 1)) - 2, pre + 1);
+        enc_bypass(c, v % (1 << k), k);
+    } else {
+        int len = k, t;
+        v -= 3 << k;
+        for (; v >= (1 << len); len++) v -= 1 << len;
+        t = 4 + len - k;
+        enc_bypass(c, (1 << t) - 2, t);
+        enc_bypass(c, v, len);
+    }
+}
+
+/* residual_coding() for one luma TU; lev has stride ls  [ref HEVCe.c:1127-1151, 1173-1269] */
+static void put_residual(Coder *c, Ctxs *x, int n, int mode, const int *lev, int ls) {
+    const uint8_t (*scan)[2];
+    uint8_t cgsig[8][8];
+    int kind = 0 /* 0 diag 1 hor 2 ver */, i, last = 0, ncg = n >> 2;
+    int nz = 0, signs = 0, nb = 0, c1 = 1, absv[16];
+    if (n <= 8) { if (iabs(mode - M_VER) <= 4) kind = 1; else if (iabs(mode - M_HOR) <= 4) kind = 2; }
+    scan = kind == 1 ? SCAN_H8 : kind == 2 ? SCAN_V8 : n == 4 ? SCAN_D4 : n == 8 ? SCAN_D8 : n == 16 ? SCAN_D16 : SCAN_D32;
+    memset(cgsig, 0, sizeof cgsig);
+    for (i = 0; i < n * n; i++)
+        if (lev[scan[i][0] * ls + scan[i][1]]) { cgsig[scan[i][0] >> 2][scan[i][1] >> 2] = 1; last = i; }
+    put_last_pos(c, x, n, kind == 2, scan[last][0], scan[last][1]);
+
+    for (i = last; i >= 0; i--) {
+        const int y = scan[i][0], xx = scan[i][1], gy = y >> 2, gx = xx >> 2;
+        const int v = lev[y * ls + xx];
+        const int first_cg = (gy | gx) == 0, at_last = (i == last);
+        const int cg_first = (i & 15) == 0, cg_enter = ((i & 15) == 15) || at_last;
+        if (cg_enter) {
+            int right = gx < ncg - 1 && cgsig[gy][gx + 1], below = gy < ncg - 1 && cgsig[gy + 1][gx];
+            nb = (below << 1) | right; nz = 0; signs = 0;
+            if (!first_cg && !at_last) enc_bin(c, &x->s[CX_SIGCG + (nb != 0)], cgsig[gy][gx]);
+        }
+        if (!at_last && (first_cg || (cgsig[gy][gx] && (!cg_first || nz > 0))))
+            enc_bin(c, &x->s[CX_SIG + sig_ctx_index(n, kind == 0, y, xx, nb)], v != 0);
+        if (v) { absv[nz++] = iabs(v); signs = (signs << 1) | (v < 0); }
+        if (cg_first && nz > 0) {
+            const int set = (first_cg ? 0 : 2) + (c1 == 0);
+            int esc = nz > 8, g2 = -1, j;
+            c1 = 1;
+            for (j = 0; j < 8 && j < nz; j++) {
+                enc_bin(c, &x->s[CX_ONE + 4 * set + c1], absv[j] > 1);
+                if (absv[j] > 1) { c1 = 0; if (g2 < 0) g2 = absv[j] > 2; else esc = 1; }
+                else if (c1 > 0 && c1 < 3) c1++;
+            }
+            if (c1 == 0 && g2 >= 0) { enc_bin(c, &x->s[CX_ABS + set], g2); esc |= g2; }
+            enc_bypass(c, signs, nz);
+            if (esc) {
+                int base = 3, rice = 0;
+                for (j = 0; j < nz; j++) {
+                    int rem = absv[j] - (j < 8 ? base : 1);
+                    if (rem >= 0) {
+                        put_remainder(c, rem, rice);
+                        if (absv[j] > (3 << rice)) rice = imin(rice + 1, 4);
+                    }
+                    if (absv[j] >= 2) base = 2;
+                }
+            }
+        }
+    }
+}
+
+static int any_nonzero(int n, const int *lev, int ls) {
+    int i, j;
+    for (i = 0; i < n; i++) for (j = 0; j < n; j++) if (lev[i * ls + j]) return 1;
+    return 0;
+}
+
+static void put_split_cu(Coder *c, Ctxs *x, int n, int flag, int ctxinc) {    /* [ref HEVCe.c:943-947] */
+    if (n >= 16) enc_bin(c, &x->s[CX_SPLIT_CU + ctxinc], flag);
+}
+
+/* coding_unit() body after split_cu_flag.  kind: 0 = 2Nx2N one TU, 1 = 2Nx2N four TUs, 2 = NxN
+   lev = CU-sized level array of stride ls in natural position  [ref HEVCe.c:1272-1340] */
+static void put_cu(Coder *c, Ctxs *x, int n, int kind, const int *mode, const int *left, const int *above, const int *lev, int ls) {
+    int s;
+    if (n == 8) enc_bin(c, &x->s[CX_PART], kind != 2);
+    put_luma_modes(c, x, kind == 2 ? 4 : 1, mode, left, above);
+    enc_bin(c, &x->s[CX_UVPM], 0);
+    if (kind != 2) enc_bin(c, &x->s[CX_SPLIT_TU + (n == 32 ? 0 : n == 16 ? 1 : 2)], kind == 1);
+    enc_bin(c, &x->s[CX_UVCBF], 0);
+    enc_bin(c, &x->s[CX_UVCBF], 0);
+    if (kind == 0) {
+        int cbf = any_nonzero(n, lev, ls);
+        enc_bin(c, &x->s[CX_YCBF + 1], cbf);
+        if (cbf) put_residual(c, x, n, mode[0], lev, ls);
+    } else {
+        const int h = n >> 1;
+        for (s = 0; s < 4; s++) {
+            const int *sub = lev + (s >> 1) * h * ls + (s & 1) * h;
+            int cbf = any_nonzero(h, sub, ls);
+            enc_bin(c, &x->s[CX_YCBF + 0], cbf);
+            if (cbf) put_residual(c, x, h, mode[kind == 2 ? s : 0], sub, ls);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* decision records                                                           */
+/* ------------------------------------------------------------------------- */
+/* per CTU: 1024 int16 levels in natural position, 64 luma modes (per 4x4), 64 cu-info bytes (per 4x4):
+   bits 0-1 = log2(cu size)-3, bit 2 = NxN partition, bit 3 = transform split */
+enum { REC_BYTES = 2176 };
+typedef struct { int16_t lev[32][32]; uint8_t mode[8][8]; uint8_t info[8][8]; } Record;
+
+/* ------------------------------------------------------------------------- */
+/* analysis                                                                   */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int q, W, H, srcW, srcH, mw;       /* mw = W/4 (map stride) */
+    const uint8_t *src;
+    uint8_t *rec;                      /* padded reconstruction, stride W */
+    uint8_t *cumap, *pmmap;            /* per-4x4 maps of CU size and luma mode */
+    Coder cod; Ctxs cx;                /* committed counting state */
+    Ctxs fresh;                        /* contexts at slice start (NxN sub-search) */
+    uint8_t org[32][32];               /* current CTU, edge-replicated */
+    Record *rec_out;                   /* current CTU record */
+    int cy, cx0;                       /* CTU origin */
+} Enc;
+
+static int src_at(const Enc *E, int y, int x) {                /* [ref HEVCe.c:119,1622] clamped read */
+    y = y < 0 ? 0 : (y > E->srcH - 1 ? E->srcH - 1 : y);
+    x = x < 0 ? 0 : (x > E->srcW - 1 ? E->srcW - 1 : x);
+    return E->src[(size_t)y * E->srcW + x];
+}
+static int block_sse(const Enc *E, int y, int x, int n) {
+    int i, j, s = 0;
+    for (i = 0; i < n; i++) for (j = 0; j < n; j++) {
+        int d = (int)E->org[y - E->cy + i][x - E->cx0 + j] - E->rec[(size_t)(y + i) * E->W + x + j];
+        s += d * d;
+    }
+    return s;
+}
+static void fill_maps(Enc *E, int y, int x, int n, int cusz, int mode) {
+    int i, j;
+    for (i = 0; i < n / 4; i++) for (j = 0; j < n / 4; j++) {
+        size_t k = (size_t)(y / 4 + i) * E->mw + x / 4 + j;
+        if (cusz >= 0) E->cumap[k] = (uint8_t)cusz;
+        if (mode >= 0) E->pmmap[k] = (uint8_t)mode;
+    }
+}
+/* neighbour context reads with the reference's line-buffer semantics (DESIGN.md "quirks"):
+   CU size: 32 outside the picture; mode: DC outside the picture AND across a CTU-row boundary */
+static int cu_left(const Enc *E, int y, int x)  { return x == 0 ? 32 : E->cumap[(size_t)(y / 4) * E->mw + x / 4 - 1]; }
+static int cu_above(const Enc *E, int y, int x) { return y == 0 ? 32 : E->cumap[(size_t)(y / 4 - 1) * E->mw + x / 4]; }
+static int pm_left(const Enc *E, int y, int x)  { return x == 0 ? M_DC : E->pmmap[(size_t)(y / 4) * E->mw + x / 4 - 1]; }
+static int pm_above(const Enc *E, int y, int x) { return (y % CTU) == 0 ? M_DC : E->pmmap[(size_t)(y / 4 - 1) * E->mw + x / 4]; }
+
+static void store_record(Enc *E, int y, int x, int n, int kind, const int *modes, const int *lev /* n x n */) {
+    int i, j, ry = y - E->cy, rx = x - E->cx0;
+    for (i = 0; i < n; i++) for (j = 0; j < n; j++) E->rec_out->lev[ry + i][rx + j] = (int16_t)lev[i * n + j];
+    for (i = 0; i < n / 4; i++) for (j = 0; j < n / 4; j++) {
+        int sub = (kind == 2) ? (((i * 4) >= n / 2) * 2 + ((j * 4) >= n / 2)) : 0;
+        E->rec_out->mode[ry / 4 + i][rx / 4 + j] = (uint8_t)modes[sub];
+        E->rec_out->info[ry / 4 + i][rx / 4 + j] = (uint8_t)((log2i(n) - 3) | (kind == 2 ? 4 : 0) | (kind == 1 ? 8 : 0));
+    }
+}
+
+/* availability of the four sub-blocks in z-order  [ref HEVCe.c:1376-1379] */
+static void sub_avail(int s, int L, int LB, int A, int AR, int *l, int *lb, int *a, int *ar) {
+    *l  = (s & 1) ? 1 : L;
+    *lb = (s == 0) ? L : (s == 2 ? LB : 0);
+    *a  = (s & 2) ? 1 : A;
+    *ar = (s == 0) ? A : (s == 1 ? AR : (s == 2 ? 1 : 0));
+}
+
+/* [ref HEVCe.c:1350-1560] */
+static void search_cu(Enc *E, int y, int x, int n, int L, int LB, int A, int AR) {
+    const Coder c0 = E->cod;
+    const Ctxs  x0 = E->cx;
+    const int q = E->q, h = n >> 1, W = E->W;
+    const int split_inc = (n > cu_left(E, y, x)) + (n > cu_above(E, y, x));
+    const int ml = pm_left(E, y, x), ma = pm_above(E, y, x);
+    const uint8_t *org = &E->org[y - E->cy][x - E->cx0];
+    uint8_t *rec = E->rec + (size_t)y * W + x;
+    uint8_t keep[32 * 32], trial[32 * 32];
+    int lev[32 * 32];
+    Refs R;
+    int best = I32MAX, m, s, i, j;
+
+    /* 1: split into four CUs */
+    if (n > 8) {
+        put_split_cu(&E->cod, &E->cx, n, 1, split_inc);
+        for (s = 0; s < 4; s++) {
+            int l, lb, a, ar;
+            sub_avail(s, L, LB, A, AR, &l, &lb, &a, &ar);
+            search_cu(E, y + (s >> 1) * h, x + (s & 1) * h, h, l, lb, a, ar);
+        }
+        best = rd_cost(q, block_sse(E, y, x, n), (int)(coder_bits(&E->cod) - coder_bits(&c0)));
+        for (i = 0; i < n; i++) memcpy(keep + i * n, rec + (size_t)i * W, (size_t)n);
+    }
+
+    /* 2: one PU, one TU, all 35 modes */
+    fetch_refs(&R, n, rec, W, L, LB, A, AR);
+    for (m = 0; m < NMODES; m++) {
+        Coder tc = c0; Ctxs tx = x0;
+        int sse = tu_trial(q, n, m, &R, org, CTU, lev, trial), cost;
+        put_split_cu(&tc, &tx, n, 0, split_inc);
+        put_cu(&tc, &tx, n, 0, &m, &ml, &ma, lev, n);
+        cost = rd_cost(q, sse, (int)(coder_bits(&tc) - coder_bits(&c0)));
+        if (best >= cost) {
+            best = cost; E->cod = tc; E->cx = tx;
+            memcpy(keep, trial, (size_t)n * n);
+            fill_maps(E, y, x, n, n, m);
+            store_record(E, y, x, n, 0, &m, lev);
+        }
+    }
+
+    /* 3: one PU, four TUs (each predicted from the previous ones' reconstruction, in place) */
+    for (m = 0; m < NMODES; m++) {
+        Coder tc = c0; Ctxs tx = x0;
+        int cost;
+        for (s = 0; s < 4; s++) {
+            int l, lb, a, ar, sub[16 * 16];
+            uint8_t *srec = rec + (size_t)(s >> 1) * h * W + (s & 1) * h;
+            sub_avail(s, L, LB, A, AR, &l, &lb, &a, &ar);
+            fetch_refs(&R, h, srec, W, l, lb, a, ar);
+            tu_trial(q, h, m, &R, org + (s >> 1) * h * CTU + (s & 1) * h, CTU, sub, trial);
+            for (i = 0; i < h; i++) {
+                memcpy(srec + (size_t)i * W, trial + i * h, (size_t)h);
+                for (j = 0; j < h; j++) lev[((s >> 1) * h + i) * n + (s & 1) * h + j] = sub[i * h + j];
+            }
+        }
+        put_split_cu(&tc, &tx, n, 0, split_inc);
+        put_cu(&tc, &tx, n, 1, &m, &ml, &ma, lev, n);
+        cost = rd_cost(q, block_sse(E, y, x, n), (int)(coder_bits(&tc) - coder_bits(&c0)));
+        if (best >= cost) {
+            best = cost; E->cod = tc; E->cx = tx;
+            for (i = 0; i < n; i++) memcpy(keep + i * n, rec + (size_t)i * W, (size_t)n);
+            fill_maps(E, y, x, n, n, m);
+            store_record(E, y, x, n, 1, &m, lev);
+        }
+    }
+
+    /* 4: four PUs (8x8 CU only); each sub-mode is chosen with a fresh coder and fresh contexts */
+    if (n == 8) {
+        Coder tc = c0; Ctxs tx = x0;
+        int modes[4] = { -1, -1, -1, -1 }, lefts[4], aboves[4], cost;
+        for (s = 0; s < 4; s++) {
+            int l, lb, a, ar, sub[16], sbest = I32MAX;
+            uint8_t *srec = rec + (size_t)(s >> 1) * 4 * W + (s & 1) * 4;
+            sub_avail(s, L, LB, A, AR, &l, &lb, &a, &ar);
+            fetch_refs(&R, 4, srec, W, l, lb, a, ar);
+            for (m = 0; m < NMODES; m++) {
+                Coder nc; Ctxs nx = E->fresh;
+                int sse, scost;
+                coder_init(&nc, NULL);
+                sse = tu_trial(q, 4, m, &R, org + (s >> 1) * 4 * CTU + (s & 1) * 4, CTU, sub, trial);
+                put_residual(&nc, &nx, 4, m, sub, 4);           /* also for an all-zero block */
+                scost = rd_cost(q, sse, (int)coder_bits(&nc));
+                if (sbest >= scost) {
+                    sbest = scost; modes[s] = m;
+                    for (i = 0; i < 4; i++) {
+                        memcpy(srec + (size_t)i * W, trial + i * 4, 4);
+                        for (j = 0; j < 4; j++) lev[((s >> 1) * 4 + i) * 8 + (s & 1) * 4 + j] = sub[i * 4 + j];
+                    }
+                }
+            }
+        }
+        lefts[0] = ml;        aboves[0] = ma;
+        lefts[1] = modes[0];  aboves[1] = pm_above(E, y, x + 4);
+        lefts[2] = pm_left(E, y + 4, x);  aboves[2] = modes[0];
+        lefts[3] = modes[2];  aboves[3] = modes[1];
+        put_split_cu(&tc, &tx, n, 0, split_inc);
+        put_cu(&tc, &tx, n, 2, modes, lefts, aboves, lev, 8);
+        cost = rd_cost(q, block_sse(E, y, x, n), (int)(coder_bits(&tc) - coder_bits(&c0)));
+        if (best >= cost) {
+            E->cod = tc; E->cx = tx;
+            fill_maps(E, y, x, 8, 8, -1);
+            for (s = 0; s < 4; s++) fill_maps(E, y + (s >> 1) * 4, x + (s & 1) * 4, 4, -1, modes[s]);
+            store_record(E, y, x, 8, 2, modes, lev);
+            return;                                            /* reconstruction already in place */
+        }
+    }
+    for (i = 0; i < n; i++) memcpy(rec + (size_t)i * W, keep + i * n, (size_t)n);
+}
+
+/* ------------------------------------------------------------------------- */
+/* stream header  [ref HEVCe.c:625-691]                                       */
+/* ------------------------------------------------------------------------- */
+typedef struct { uint8_t *p; int acc, nacc; } BitW;
+static void bw_put(BitW *b, unsigned v, int n) {
+    for (n--; n >= 0; n--) {
+        b->acc = (b->acc << 1) | ((v >> n) & 1);
+        if (++b->nacc == 8) { *b->p++ = (uint8_t)b->acc; b->acc = 0; b->nacc = 0; }
+    }
+}
+static void bw_ue(BitW *b, unsigned v) {              /* Exp-Golomb ue(v) */
+    int len = 0; unsigned t;
+    v++;
+    for (t = v; t > 1; t >>= 1) len++;
+    bw_put(b, 0, len); bw_put(b, v, len + 1);
+}
+static int write_headers(uint8_t *out, int q, int H, int W) {
+    static const uint8_t vps[] = { 0,0,1,0x40,1,0x0c,1,0xff,0xff,3,0x10,0,0,3,0,0,3,0,0,3,0,0,3,0,0xb4,0xf0,0x24 };
+    static const uint8_t sps[] = { 0,0,1,0x42,1,1,3,0x10,0,0,3,0,0,3,0,0,3,0,0,3,0,0xb4 };
+    static const uint8_t pps[] = { 0,0,1,0x44,1,0xc0,0x90,0x91,0x81,0xd9,0x20 };
+    static const uint8_t slice_tail[5][2] = { {0x16,0xde}, {0x10,0xde}, {0x2b,0x78}, {0x4d,0xe0}, {0x97,0x80} };
+    BitW b;
+    uint8_t *p = out;
+    memcpy(p, vps, sizeof vps); p += sizeof vps;
+    memcpy(p, sps, sizeof sps); p += sizeof sps;
+    b.p = p; b.acc = 0; b.nacc = 0;
+    bw_put(&b, 0xa, 4);            /* sps id ue(0)=1, chroma_format_idc ue(1)=010, ... */
+    bw_ue(&b, (unsigned)W); bw_ue(&b, (unsigned)H);
+    bw_put(&b, 0x197ee4, 22);
+    bw_put(&b, 0x681ed1, 24);      /* ... max_transform_hierarchy_depth_intra = 1 */
+    if (b.nacc) bw_put(&b, 0, 8 - b.nacc);
+    p = b.p;
+    memcpy(p, pps, sizeof pps); p += sizeof pps;
+    { static const uint8_t sh[] = { 0,0,1,0x26,1,0xac }; memcpy(p, sh, 6); p += 6; }
+    *p++ = slice_tail[q][0]; *p++ = slice_tail[q][1];
+    return (int)(p - out);
+}
+
+/* ------------------------------------------------------------------------- */
+/* writer: replay of decision records                                         */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int q, W, H, mw;
+    uint8_t *cumap, *pmmap;
+    Coder cod; Ctxs cx;
+} Wr;
+static int wcu_left(const Wr *w, int y, int x)  { return x == 0 ? 32 : w->cumap[(size_t)(y / 4) * w->mw + x / 4 - 1]; }
+static int wcu_above(const Wr *w, int y, int x) { return y == 0 ? 32 : w->cumap[(size_t)(y / 4 - 1) * w->mw + x / 4]; }
+static int wpm_left(const Wr *w, int y, int x)  { return x == 0 ? M_DC : w->pmmap[(size_t)(y / 4) * w->mw + x / 4 - 1]; }
+static int wpm_above(const Wr *w, int y, int x) { return (y % CTU) == 0 ? M_DC : w->pmmap[(size_t)(y / 4 - 1) * w->mw + x / 4]; }
+
+static void replay_cu(Wr *w, const Record *r, int cy, int cx0, int y, int x, int n) {
+    const int ry = y - cy, rx = x - cx0, i4 = ry / 4, j4 = rx / 4;
+    const int info = r->info[i4][j4], cun = 8 << (info & 3);
+    const int inc = (n > wcu_left(w, y, x)) + (n > wcu_above(w, y, x));
+    int lev[32 * 32], i, j, s;
+    if (cun < n) {
+        put_split_cu(&w->cod, &w->cx, n, 1, inc);
+        for (s = 0; s < 4; s++) replay_cu(w, r, cy, cx0, y + (s >> 1) * (n / 2), x + (s & 1) * (n / 2), n / 2);
+        return;
+    }
+    put_split_cu(&w->cod, &w->cx, n, 0, inc);
+    for (i = 0; i < n; i++) for (j = 0; j < n; j++) lev[i * n + j] = r->lev[ry + i][rx + j];
+    if (info & 4) {
+        int modes[4], lefts[4], aboves[4];
+        for (s = 0; s < 4; s++) modes[s] = r->mode[i4 + (s >> 1)][j4 + (s & 1)];
+        lefts[0] = wpm_left(w, y, x);      aboves[0] = wpm_above(w, y, x);
+        lefts[1] = modes[0];               aboves[1] = wpm_above(w, y, x + 4);
+        lefts[2] = wpm_left(w, y + 4, x);  aboves[2] = modes[0];
+        lefts[3] = modes[2];               aboves[3] = modes[1];
+        put_cu(&w->cod, &w->cx, n, 2, modes, lefts, aboves, lev, n);
+    } else {
+        int m = r->mode[i4][j4], ml = wpm_left(w, y, x), ma = wpm_above(w, y, x);
+        put_cu(&w->cod, &w->cx, n, (info & 8) ? 1 : 0, &m, &ml, &ma, lev, n);
+    }
+    for (i = 0; i < n / 4; i++) for (j = 0; j < n / 4; j++) {
+        size_t k = (size_t)(y / 4 + i) * w->mw + x / 4 + j;
+        w->cumap[k] = (uint8_t)n;
+        w->pmmap[k] = r->mode[i4 + i][j4 + j];
+    }
+}
+
+/* records (raster CTU order) -> complete .h265; returns its length */
+ORC_API int orc_write_stream(uint8_t *out, const uint8_t *records, int H, int W, int q) {
+    Wr w;
+    int y, x, k = 0, len;
+    build_tables();
+    w.q = q; w.W = W; w.H = H; w.mw = W / 4;
+    w.cumap = (uint8_t *)malloc((size_t)(H / 4) * w.mw);
+    w.pmmap = (uint8_t *)malloc((size_t)(H / 4) * w.mw);
+    len = write_headers(out, q, H, W);
+    coder_init(&w.cod, out + len);
+    ctxs_init(&w.cx, q);
+    for (y = 0; y < H; y += CTU)
+        for (x = 0; x < W; x += CTU, k++) {
+            replay_cu(&w, (const Record *)(records + (size_t)k * REC_BYTES), y, x, y, x, CTU);
+            enc_terminate(&w.cod, y + CTU >= H && x + CTU >= W);       /* [ref HEVCe.c:1630] */
+        }
+    coder_finish(&w.cod);
+    len += (int)w.cod.nout;
+    free(w.cumap); free(w.pmmap);
+    return len;
+}
+
+/* ------------------------------------------------------------------------- */
+/* public entry points                                                        */
+/* ------------------------------------------------------------------------- */
+/* analysis only: fills img_rcon (padded) and records (REC_BYTES per CTU, raster order);
+   state_out (optional, 8 ints per CTU): range, low, nbits, nbytes, bufbyte, zeros, nout(low 31 bits), bits since start */
+ORC_API int orc_analyse(const uint8_t *img, uint8_t *img_rcon, uint8_t *records, int32_t *state_out,
+                        int *ysz, int *xsz, int q) {
+    Enc E;
+    int y, x, i, j, k = 0;
+    build_tables();
+    memset(&E, 0, sizeof E);
+    E.q = q; E.srcH = *ysz; E.srcW = *xsz; E.src = img;
+    E.H = (imin(*ysz, MAXDIM) + CTU - 1) / CTU * CTU;           /* [ref HEVCe.c:1581-1582] */
+    E.W = (imin(*xsz, MAXDIM) + CTU - 1) / CTU * CTU;
+    E.mw = E.W / 4;
+    E.rec = img_rcon;
+    E.cumap = (uint8_t *)malloc((size_t)(E.H / 4) * E.mw);
+    E.pmmap = (uint8_t *)malloc((size_t)(E.H / 4) * E.mw);
+    memset(E.cumap, 32, (size_t)(E.H / 4) * E.mw);
+    memset(E.pmmap, M_DC, (size_t)(E.H / 4) * E.mw);
+    coder_init(&E.cod, NULL);
+    ctxs_init(&E.cx, q);
+    E.fresh = E.cx;
+    for (y = 0; y < E.H; y += CTU)
+        for (x = 0; x < E.W; x += CTU, k++) {
+            for (i = 0; i < CTU; i++) for (j = 0; j < CTU; j++) E.org[i][j] = (uint8_t)src_at(&E, y + i, x + j);
+            E.rec_out = (Record *)(records + (size_t)k * REC_BYTES);
+            memset(E.rec_out, 0, REC_BYTES);
+            E.cy = y; E.cx0 = x;
+            search_cu(&E, y, x, CTU, x > 0, 0, y > 0, y > 0 && x + CTU < E.W);      /* [ref HEVCe.c:1606-1609] */
+            enc_terminate(&E.cod, y + CTU >= E.H && x + CTU >= E.W);
+            if (state_out) {
+                int32_t *s = state_out + (size_t)k * 8;
+                s[0] = E.cod.range; s[1] = (int32_t)E.cod.low; s[2] = E.cod.nbits; s[3] = E.cod.nbytes;
+                s[4] = E.cod.bufbyte; s[5] = E.cod.zeros; s[6] = (int32_t)(E.cod.nout & 0x7fffffff);
+                s[7] = (int32_t)(coder_bits(&E.cod) & 0x7fffffff);
+            }
+        }
+    free(E.cumap); free(E.pmmap);
+    *ysz = E.H; *xsz = E.W;
+    return k;
+}
+
+/* same contract as the reference's HEVCImageEncoder  [ref HEVCe.h:5-12, HEVCe.c:1570-1647] */
+ORC_API int orc_HEVCImageEncoder(uint8_t *pbuffer, const uint8_t *img, uint8_t *img_rcon, int *ysz, int *xsz, const int qpd6) {
+    int H = (imin(*ysz, MAXDIM) + CTU - 1) / CTU * CTU, W = (imin(*xsz, MAXDIM) + CTU - 1) / CTU * CTU;
+    size_t nctu = (size_t)(H / CTU) * (W / CTU);
+    uint8_t *records = (uint8_t *)malloc(nctu * REC_BYTES);
+    int len;
+    orc_analyse(img, img_rcon, records, NULL, ysz, xsz, qpd6);
+    len = orc_write_stream(pbuffer, records, H, W, qpd6);
+    free(records);
+    return len;
+}
+
+/* ---- function-level entry points used by the parity tests ---------------- */
+ORC_API void orc_tables(int16_t *t32 /*1024*/, uint8_t *scan_d32 /*2048*/, uint8_t *scan_h8 /*128*/, uint8_t *scan_v8 /*128*/) {
+    build_tables();
+    memcpy(t32, T32, sizeof T32); memcpy(scan_d32, SCAN_D32, sizeof SCAN_D32);
+    memcpy(scan_h8, SCAN_H8, sizeof SCAN_H8); memcpy(scan_v8, SCAN_V8, sizeof SCAN_V8);
+}
+ORC_API void orc_scan(int n, int kind, uint8_t *out /* n*n*2 */) {
+    build_tables();
+    memcpy(out, kind == 1 ? (void *)SCAN_H8 : kind == 2 ? (void *)SCAN_V8 : n == 4 ? (void *)SCAN_D4 : n == 8 ? (void *)SCAN_D8
+                 : n == 16 ? (void *)SCAN_D16 : (void *)SCAN_D32, (size_t)n * n * 2);
+}
+ORC_API void orc_ctx_init(int q, uint8_t *out /* NCTX */) { Ctxs x; ctxs_init(&x, q); memcpy(out, x.s, NCTX); }
+ORC_API int  orc_rd_cost(int q, int dist, int bits) { return rd_cost(q, dist, bits); }
+/* border arrays are given explicitly: corner, left[2n], above[2n] (raw); smoothing is derived here */
+ORC_API void orc_predict(int n, int m, int corner, const uint8_t *left, const uint8_t *above, uint8_t *out) {
+    Refs R; uint8_t fake[65 * 130]; int i, rs = 130; uint8_t *blk = fake + rs + 1;
+    build_tables();
+    memset(fake, 0, sizeof fake);
+    blk[-rs - 1] = (uint8_t)corner;
+    for (i = 0; i < 2 * n; i++) { blk[i * rs - 1] = left[i]; blk[-rs + i] = above[i]; }
+    fetch_refs(&R, n, blk, rs, 1, 1, 1, 1);
+    predict_block(n, m, &R, out);
+}
+ORC_API void orc_fetch_refs(int n, const uint8_t *rec, int rs, int L, int LB, int A, int AR, uint8_t *out /* 2*(1+4n) */) {
+    Refs R; int f;
+    fetch_refs(&R, n, rec, rs, L, LB, A, AR);
+    for (f = 0; f < 2; f++) { uint8_t *o = out + f * (1 + 4 * n); o[0] = R.c[f]; memcpy(o + 1, R.l[f], 2 * n); memcpy(o + 1 + 2 * n, R.a[f], 2 * n); }
+}
+ORC_API void orc_transform(int n, int inverse, const int *in, int *out) { build_tables(); if (inverse) inv_transform(n, in, out); else fwd_transform(n, in, out); }
+ORC_API void orc_quantize(int q, int n, const int *in, int *out)   { quantize_block(q, n, in, out); }
+ORC_API void orc_dequantize(int q, int n, const int *in, int *out) { dequantize_block(q, n, in, out); }
+/* full TU trial from explicit borders; returns SSE */
+ORC_API int orc_tu_trial(int q, int n, int m, int corner, const uint8_t *left, const uint8_t *above,
+                         const uint8_t *org /* n x n */, int *lev, uint8_t *rec_out) {
+    Refs R; uint8_t fake[65 * 130]; int i, rs = 130; uint8_t *blk = fake + rs + 1;
+    build_tables();
+    memset(fake, 0, sizeof fake);
+    blk[-rs - 1] = (uint8_t)corner;
+    for (i = 0; i < 2 * n; i++) { blk[i * rs - 1] = left[i]; blk[-rs + i] = above[i]; }
+    fetch_refs(&R, n, blk, rs, 1, 1, 1, 1);
+    return tu_trial(q, n, m, &R, org, n, lev, rec_out);
+}
+/* bits a fresh coder (slice-start contexts of q) spends on residual_coding of one TU, plus its final registers */
+ORC_API int orc_residual_bits(int q, int n, int m, const int *lev, int32_t *regs /* 6, optional */, uint8_t *ctx_out /* NCTX, optional */) {
+    Coder c; Ctxs x;
+    build_tables();
+    coder_init(&c, NULL); ctxs_init(&x, q);
+    put_residual(&c, &x, n, m, lev, n);
+    if (regs) { regs[0] = c.range; regs[1] = (int32_t)c.low; regs[2] = c.nbits; regs[3] = c.nbytes; regs[4] = c.bufbyte; regs[5] = c.zeros; }
+    if (ctx_out) memcpy(ctx_out, x.s, NCTX);
+    return (int)coder_bits(&c);
+}
+/* encode a bin script with a byte-emitting coder: script = triples (kind, a, b):
+   kind 0: context bin (a = ctx index, b = bin); 1: bypass (a = bins, b = len); 2: terminate (a = bin). returns bytes incl. finish */
+ORC_API int orc_bin_script(int q, const int32_t *script, int n, uint8_t *out) {
+    Coder c; Ctxs x; int i;
+    coder_init(&c, out); ctxs_init(&x, q);
+    for (i = 0; i < n; i++) {
+        const int32_t *t = script + 3 * i;
+        if (t[0] == 0) enc_bin(&c, &x.s[t[1]], t[2]); else if (t[0] == 1) enc_bypass(&c, t[1], t[2]); else enc_terminate(&c, t[1]);
+    }
+    coder_finish(&c);
+    return (int)c.nout;
+}
+ORC_API int orc_header(uint8_t *out, int q, int H, int W) { return write_headers(out, q, H, W); }
+ORC_API int orc_record_bytes(void) { return REC_BYTES; }
+ORC_API int orc_num_ctx(void) { return NCTX; }

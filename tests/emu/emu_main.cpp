@@ -1,0 +1,117 @@
+/* TEST INFRASTRUCTURE: runs hv_analyse_image() of the product's device header on the CPU fiber emulator. */
+#define HEVCE_EMU 1
+#include "emu_rt.h"
+#include "../../hevc-image-encoder-lite_amd/csrc/hevce_device.h"
+#include <vector>
+
+int emu_cur = 0;
+int emu_stage[8][64];
+
+namespace {
+enum { NT = HV_NTHREADS, STACK = 256 * 1024 };
+enum State { RUN, WAIT_WAVE, WAIT_BLOCK, DONE };
+struct Fiber { void *sp; State st; char *stack; };
+Fiber fib[NT];
+void *sched_sp;
+int wave_wait[8], block_wait, ndone;
+HvLds *g_lds;
+const HevceImageDesc *g_im;
+
+extern "C" void emu_switch(void **save_sp, void *new_sp);
+asm(R"(
+.text
+.globl emu_switch
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+)");
+
+void yield_to_sched() { emu_switch(&fib[emu_cur].sp, sched_sp); }
+
+void fiber_entry() {
+    hv_analyse_image(*g_lds, *g_im);
+    fib[emu_cur].st = DONE;
+    ndone++;
+    yield_to_sched();
+    abort();
+}
+}  // namespace
+
+void emu_wave_sync(void) {
+    fib[emu_cur].st = WAIT_WAVE;
+    wave_wait[emu_cur >> 6]++;
+    yield_to_sched();
+}
+void emu_block_sync(void) {
+    fib[emu_cur].st = WAIT_BLOCK;
+    block_wait++;
+    yield_to_sched();
+}
+
+extern "C" __attribute__((visibility("default")))
+int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, uint8_t *records, int32_t *ctu_state) {
+    HevceImageDesc im;
+    memset(&im, 0, sizeof im);
+    im.img = img; im.rcon = rcon; im.records = records; im.ctu_state = ctu_state;
+    im.src_h = src_h; im.src_w = src_w; im.qpd6 = q;
+    im.H = ((src_h < HEVCE_MAXDIM ? src_h : HEVCE_MAXDIM) + 31) / 32 * 32;
+    im.W = ((src_w < HEVCE_MAXDIM ? src_w : HEVCE_MAXDIM) + 31) / 32 * 32;
+    std::vector<uint8_t> scratch(HEVCE_SCRATCH_BYTES, 0xCD);
+    im.scratch = scratch.data();
+    HvLds *lds = (HvLds *)aligned_alloc(64, (sizeof(HvLds) + 63) / 64 * 64);
+    memset(lds, 0xAB, sizeof(HvLds));                     /* LDS is not zero-initialised on the GPU either */
+    g_lds = lds; g_im = &im;
+    memset(wave_wait, 0, sizeof wave_wait); block_wait = 0; ndone = 0;
+    for (int i = 0; i < NT; i++) {
+        fib[i].stack = (char *)aligned_alloc(64, STACK);
+        void **sp = (void **)(fib[i].stack + STACK - 64);
+        *--sp = (void *)fiber_entry;                      /* return address for emu_switch's ret */
+        for (int k = 0; k < 6; k++) *--sp = 0;            /* rbp rbx r12..r15 */
+        fib[i].sp = sp; fib[i].st = RUN;
+    }
+    int rc = 0;
+    while (ndone < NT) {
+        bool progress = false;
+        for (int i = 0; i < NT; i++) {
+            if (fib[i].st != RUN) continue;
+            emu_cur = i;
+            emu_switch(&sched_sp, fib[i].sp);
+            progress = true;
+        }
+        for (int w = 0; w < 8; w++)
+            if (wave_wait[w] == 64) {
+                wave_wait[w] = 0;
+                for (int l = 0; l < 64; l++) fib[w * 64 + l].st = RUN;
+                progress = true;
+            }
+        if (block_wait == NT) {
+            block_wait = 0;
+            for (int i = 0; i < NT; i++) fib[i].st = RUN;
+            progress = true;
+        }
+        if (!progress) {
+            fprintf(stderr, "emu: deadlock (divergent synchronisation): block_wait=%d done=%d waves:", block_wait, ndone);
+            for (int w = 0; w < 8; w++) fprintf(stderr, " %d", wave_wait[w]);
+            fprintf(stderr, "\n");
+            rc = -1;
+            break;
+        }
+    }
+    for (int i = 0; i < NT; i++) free(fib[i].stack);
+    free(lds);
+    return rc;
+}
+extern "C" __attribute__((visibility("default"))) int emu_lds_bytes(void) { return (int)sizeof(HvLds); }

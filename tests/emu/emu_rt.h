@@ -1,0 +1,48 @@
+/*
+ * emu_rt.h -- TEST INFRASTRUCTURE: a single-threaded SIMT emulation of one 512-thread workgroup, used by the CPU
+ * test suite to exercise the control flow of hevc-image-encoder-lite_amd/csrc/hevce_device.h without a GPU.
+ * Every "thread" is a fiber (hand-rolled x86-64 context switch); a fiber runs until it reaches a wave-level or
+ * block-level synchronisation point, exactly the points where the HIP build synchronises.  Never linked into the
+ * product library; the product has no CPU path.
+ */
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define HD  static inline
+#define HDN static
+#define DEVCONST static const
+
+void emu_wave_sync(void);
+void emu_block_sync(void);
+extern int  emu_cur;                 /* running fiber = thread id */
+extern int  emu_stage[8][64];        /* shuffle staging, per wave */
+
+#define WAVE_SYNC()  emu_wave_sync()
+#define BLOCK_SYNC() emu_block_sync()
+
+HD int hv_tid() { return emu_cur; }
+HD int hv_shfl_xor(int v, int m) {
+    const int w = emu_cur >> 6, l = emu_cur & 63;
+    emu_stage[w][l] = v;
+    emu_wave_sync();
+    const int r = emu_stage[w][l ^ m];
+    emu_wave_sync();
+    return r;
+}
+HD int hv_bcast0(int v) {
+    const int w = emu_cur >> 6, l = emu_cur & 63;
+    if (l == 0) emu_stage[w][0] = v;
+    emu_wave_sync();
+    const int r = emu_stage[w][0];
+    emu_wave_sync();
+    return r;
+}
+HD int hv_atomic_inc(int *p) { return (*p)++; }
+HD int hv_mul24(int a, int b) {
+    if (a < -(1 << 23) || a >= (1 << 23) || b < -(1 << 23) || b >= (1 << 23)) { fprintf(stderr, "emu: mul24 operand out of range %d %d\n", a, b); abort(); }
+    return a * b;
+}
+HD int hv_clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
