@@ -1,0 +1,234 @@
+"""hevc-image-encoder-lite_amd -- host-side mirror of the reference's encoder interface on top of the
+MI355X-native C-ABI library (include/hevce_mi355x.h, built from csrc/ into lib/libhevce_mi355x.so).
+
+The reference's operator API is one C function, ``HEVCImageEncoder(pbuffer, img, img_rcon, *ysz, *xsz, qpd6)``
+(reference src/HEVCe.h:5-12).  ``HEVCImageEncoder`` below calls the drop-in symbol of the same name with the same
+argument meaning; ``Job`` exposes the additive batch / device-resident path.  There is no CPU fallback: without
+the HIP library or without a GPU these calls raise.
+
+The directory name contains dashes, so import it through ``hevce_pkg.load()`` at the repository root.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.environ.get("HEVCE_LIB") or os.path.join(_HERE, "lib", "libhevce_mi355x.so")   # HEVCE_LIB: diagnostics builds
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "hevce_mi355x.h")
+RECORD_BYTES = 2176
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int)
+_lib = None
+
+
+class HevceError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP kernel + host shim for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-s"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def lib():
+    """The C-ABI library; raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HevceError(f"{LIB_PATH} is missing: run hevc-image-encoder-lite_amd.build() "
+                             "(make -C hevc-image-encoder-lite_amd/csrc); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.HEVCImageEncoder.restype = C.c_int
+        L.HEVCImageEncoder.argtypes = [_u8p, _u8p, _u8p, _i32p, _i32p, C.c_int]
+        L.HEVCImageEncoderBatch.restype = C.c_int
+        L.hevce_stream_bound.restype = C.c_long
+        L.hevce_stream_bound.argtypes = [C.c_int, C.c_int]
+        L.hevce_job_create.restype = C.c_void_p
+        L.hevce_job_create.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _i32p]
+        L.hevce_job_destroy.argtypes = [C.c_void_p]
+        L.hevce_job_upload.argtypes = [C.c_void_p, C.c_int, _u8p]
+        L.hevce_job_set_device_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.hevce_job_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        for f in ("hevce_job_run", "hevce_job_launch", "hevce_job_finish"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.hevce_job_stream.restype = _u8p
+        L.hevce_job_stream.argtypes = [C.c_void_p, C.c_int, _i32p]
+        L.hevce_job_padded_size.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p]
+        L.hevce_job_download_rcon.argtypes = [C.c_void_p, C.c_int, _u8p]
+        L.hevce_job_device_rcon.restype = C.c_void_p
+        L.hevce_job_device_rcon.argtypes = [C.c_void_p, C.c_int]
+        L.hevce_job_device_records.restype = C.c_void_p
+        L.hevce_job_device_records.argtypes = [C.c_void_p, C.c_int]
+        L.hevce_job_download_records.argtypes = [C.c_void_p, C.c_int, _u8p, _i32p]
+        L.hevce_job_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.hevce_job_dump.restype = C.c_long
+        L.hevce_job_dump.argtypes = [C.c_void_p, _i32p, C.c_long]
+        L.hevce_job_poll.argtypes = [C.c_void_p]
+        L.hevce_job_trace.argtypes = [C.c_void_p, C.c_int, _i32p]
+        L.hevce_write_stream.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
+        L.hevce_write_header.argtypes = [_u8p, C.c_int, C.c_int, C.c_int]
+        L.hevce_last_error.restype = C.c_char_p
+        L.hevce_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _p(a, t=_u8p):
+    return a.ctypes.data_as(t)
+
+
+def pad32(v):
+    return (min(int(v), 8192) + 31) // 32 * 32
+
+
+def device_count():
+    return int(lib().hevce_device_count())
+
+
+def _check(rc, what):
+    if rc is None or (isinstance(rc, int) and rc < 0):
+        raise HevceError(f"{what} failed: {lib().hevce_last_error().decode()}")
+
+
+def HEVCImageEncoder(img, qpd6):
+    """Drop-in call: returns (stream bytes, padded reconstruction [yszn, xszn] uint8).
+
+    Same contract as reference src/HEVCe.c:1570-1647: img is 8-bit luma [ysz, xsz]; the reconstruction has the
+    padded size (multiples of 32); sizes above 8192 are cropped; qpd6 in 0..4."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    H, W = pad32(h), pad32(w)
+    out = np.empty(int(lib().hevce_stream_bound(h, w)), np.uint8)
+    rcon = np.empty((H, W), np.uint8)
+    ys, xs = C.c_int(h), C.c_int(w)
+    n = lib().HEVCImageEncoder(_p(out), _p(img), _p(rcon), C.byref(ys), C.byref(xs), int(qpd6))
+    _check(n, "HEVCImageEncoder")
+    assert (ys.value, xs.value) == (H, W)
+    return out[:n].tobytes(), rcon
+
+
+def write_stream(records, H, W, qpd6):
+    """Host stream writer alone (no GPU needed): decision records -> .h265 bytes."""
+    records = np.ascontiguousarray(records, np.uint8)
+    out = np.empty(256 + (H // 32) * (W // 32) * 3200 + 16, np.uint8)
+    n = lib().hevce_write_stream(_p(out), _p(records), H, W, int(qpd6))
+    return out[:n].tobytes()
+
+
+def write_header(qpd6, H, W):
+    out = np.zeros(256, np.uint8)
+    n = lib().hevce_write_header(_p(out), int(qpd6), H, W)
+    return out[:n].tobytes()
+
+
+class Job:
+    """A batch of independent images resident in HBM: one workgroup per image (additive API)."""
+
+    def __init__(self, sizes, qpd6, device=0):
+        self.n = len(sizes)
+        self.sizes = [(int(h), int(w)) for h, w in sizes]
+        q = [int(qpd6)] * self.n if np.isscalar(qpd6) else [int(v) for v in qpd6]
+        self.qpd6 = q
+        ys = (C.c_int * self.n)(*[s[0] for s in self.sizes])
+        xs = (C.c_int * self.n)(*[s[1] for s in self.sizes])
+        qs = (C.c_int * self.n)(*q)
+        self._h = lib().hevce_job_create(int(device), self.n, ys, xs, qs)
+        if not self._h:
+            raise HevceError(f"hevce_job_create failed: {lib().hevce_last_error().decode()}")
+        self._keep = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().hevce_job_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def upload(self, i, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.shape == self.sizes[i]
+        _check(lib().hevce_job_upload(self._h, i, _p(img)), "hevce_job_upload")
+
+    def set_device_image(self, i, ptr, keepalive=None):
+        """Use an image already in HBM (e.g. torch tensor .data_ptr())."""
+        self._keep[i] = keepalive
+        _check(lib().hevce_job_set_device_image(self._h, i, C.c_void_p(ptr)), "hevce_job_set_device_image")
+
+    def set_stream(self, hip_stream):
+        _check(lib().hevce_job_set_stream(self._h, C.c_void_p(hip_stream)), "hevce_job_set_stream")
+
+    def run(self):
+        _check(lib().hevce_job_run(self._h), "hevce_job_run")
+
+    def launch(self):
+        _check(lib().hevce_job_launch(self._h), "hevce_job_launch")
+
+    def finish(self):
+        _check(lib().hevce_job_finish(self._h), "hevce_job_finish")
+
+    def dump(self, nctu):
+        out = np.zeros(nctu * 21 * 72 * 16, np.int32)
+        n = lib().hevce_job_dump(self._h, _p(out, _i32p), out.size)
+        return None if n < 0 else out.reshape(nctu, 21, 72, 16)
+
+    def poll(self):
+        return bool(lib().hevce_job_poll(self._h))
+
+    def trace(self, i=0):
+        out = np.zeros(256, np.int32)
+        if lib().hevce_job_trace(self._h, i, _p(out, _i32p)) != 0:
+            return None
+        return out
+
+    def stream(self, i):
+        n = C.c_int(0)
+        p = lib().hevce_job_stream(self._h, i, C.byref(n))
+        return C.string_at(p, n.value)
+
+    def padded_size(self, i):
+        return pad32(self.sizes[i][0]), pad32(self.sizes[i][1])
+
+    def rcon(self, i):
+        H, W = self.padded_size(i)
+        out = np.empty((H, W), np.uint8)
+        _check(lib().hevce_job_download_rcon(self._h, i, _p(out)), "hevce_job_download_rcon")
+        return out
+
+    def records(self, i):
+        H, W = self.padded_size(i)
+        nctu = (H // 32) * (W // 32)
+        rec = np.empty((nctu, RECORD_BYTES), np.uint8)
+        st = np.empty((nctu, 8), np.int32)
+        _check(lib().hevce_job_download_records(self._h, i, _p(rec), _p(st, _i32p)), "hevce_job_download_records")
+        return rec, st
+
+    def device_rcon_ptr(self, i):
+        return lib().hevce_job_device_rcon(self._h, i)
+
+    def timings(self):
+        k, d, w = C.c_float(), C.c_float(), C.c_float()
+        lib().hevce_job_timings(self._h, C.byref(k), C.byref(d), C.byref(w))
+        return dict(kernel_ms=k.value, d2h_ms=d.value, writer_ms=w.value)
+
+
+def encode_batch(imgs, qpd6, device=0):
+    """Encode independent images in one launch; returns [(stream, rcon), ...]."""
+    with Job([im.shape for im in imgs], qpd6, device) as job:
+        for i, im in enumerate(imgs):
+            job.upload(i, im)
+        job.run()
+        return [(job.stream(i), job.rcon(i)) for i in range(job.n)]

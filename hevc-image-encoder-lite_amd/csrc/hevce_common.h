@@ -59,6 +59,8 @@ typedef struct HevceImageDesc {
     int32_t       *ctu_state; /* optional: 8 ints per CTU (coder registers after the CTU) */
     uint8_t       *scratch;   /* HEVCE_SCRATCH_BYTES of per-image trial scratch */
     int32_t src_h, src_w, H, W, qpd6, status;
+    int32_t       *dump;      /* diagnostics: per CU evaluation, 72 x (sse, cost) ints (NULL = off) */
+    int32_t       *trace;     /* diagnostics: host-pinned, 16 ints per wavefront (only written by HEVCE_TRACE builds) */
 } HevceImageDesc;
 
 #define HEVCE_TRIALS        72                               /* 35 + 35 + 1 (+1 pad) trial slots */

@@ -14,6 +14,7 @@
  */
 #pragma once
 #include "hevce_common.h"
+#include "hevce_tables.h"
 
 #ifdef HEVCE_EMU
 #include "emu_rt.h"
@@ -22,15 +23,39 @@
 #define HD  __device__ __forceinline__
 #define HDN __device__ __noinline__
 #define DEVCONST __constant__ const
+/* WAVE_SYNC: lanes of ONE wavefront exchange data through memory.  TU jobs write levels / reconstruction through generic
+   pointers (flat stores into LDS or HBM) and other lanes read them back with ds_/flat loads; flat and DS operations of a
+   wave are not ordered against each other, so the fence must drain both counters (workgroup-scope release/acquire =
+   s_waitcnt vmcnt(0) lgkmcnt(0)), not merely stop compiler reordering. */
+#ifdef HEVCE_WSYNC_WEAK
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+#endif
+#ifdef HEVCE_BSYNC_AGENT
+#define BLOCK_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_barrier(); \
+                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
+#else
 #define BLOCK_SYNC() __syncthreads()
+#endif
 static HD int  hv_tid() { return (int)threadIdx.x; }
 static HD int  hv_shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 static HD int  hv_bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }   /* lane 0's value, wave-uniform (SGPR) */
 static HD int  hv_atomic_inc(int *p) { return atomicAdd(p, 1); }
 static HD int  hv_mul24(int a, int b) { return __mul24(a, b); }
 static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v == 0 */
+#endif
+
+/* diagnostics: -DHEVCE_TRACE makes lane 0 of every wavefront publish its last checkpoint to host-pinned memory */
+#if defined(HEVCE_TRACE) && !defined(HEVCE_EMU)
+#define HV_TRACE(S, slotno, code) do { if ((S).trace && (hv_tid() & 63) == 0) { \
+        volatile int *t_ = (volatile int *)(S).trace + (hv_tid() >> 6) * 16; t_[slotno] = (code); t_[15] += 1; __threadfence_system(); } } while (0)
+#define HV_TRACE_LANE(S, idx, code) do { if ((S).trace) { volatile int *t_ = (volatile int *)(S).trace; t_[128 + (idx)] = (code); __threadfence_system(); } } while (0)
+#else
+#define HV_TRACE(S, slotno, code) do { } while (0)
+#define HV_TRACE_LANE(S, idx, code) do { } while (0)
 #endif
 
 #define HV_NTHREADS 512
@@ -70,35 +95,18 @@ constexpr HvTMats hv_make_tmats() {
 DEVCONST HvTMats hv_tm = hv_make_tmats();
 
 /* H.265 table 9-46 (rangeTabLps), four bytes per state packed little-endian; table 9-47 (transIdxLps) */
-DEVCONST unsigned hv_lps4[64] = {
-    0xf0d0b080u, 0xe3c5a780u, 0xd8bb9e80u, 0xcdb2967bu, 0xc3a98e74u, 0xb9a0876fu, 0xaf988069u, 0xa6907a64u,
-    0x9e89745fu, 0x96826e5au, 0x8e7b6855u, 0x87756351u, 0x806f5e4du, 0x7a695949u, 0x74645545u, 0x6e5f5042u,
-    0x685a4c3eu, 0x6356483bu, 0x5e514538u, 0x594d4135u, 0x55493e33u, 0x50453b30u, 0x4c42382eu, 0x483f352bu,
-    0x453b3229u, 0x41383027u, 0x3e362d25u, 0x3b332b23u, 0x38302921u, 0x352e2720u, 0x322b251eu, 0x3029231du,
-    0x2d27211bu, 0x2b251f1au, 0x29231e18u, 0x27211c17u, 0x25201b16u, 0x231e1a15u, 0x211d1814u, 0x1f1b1713u,
-    0x1e1a1612u, 0x1c191511u, 0x1b171410u, 0x1916130fu, 0x1815120eu, 0x1714110eu, 0x1613100du, 0x15120f0cu,
-    0x14110e0cu, 0x13100e0bu, 0x120f0d0bu, 0x110f0c0au, 0x100e0c0au, 0x0f0d0b09u, 0x0e0c0b09u, 0x0e0c0a08u,
-    0x0d0b0908u, 0x0c0b0907u, 0x0c0a0907u, 0x0b0a0807u, 0x0b090806u, 0x0a090706u, 0x09080706u, 0x02020202u };
-DEVCONST u8 hv_lpsnext[64] = {
-     0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9,11,11,12,13,13,15,15,16,16,18,18,19,19,21,21,22,22,23,24,
-    24,25,26,26,27,27,28,29,29,30,30,30,31,32,32,33,33,33,34,34,35,35,35,36,36,36,37,37,37,38,38,63 };
+DEVCONST unsigned hv_lps4[64] = HEVCE_TAB_LPS4;
+DEVCONST u8 hv_lpsnext[64] = HEVCE_TAB_LPSNEXT;
 /* H.265 9.3.2.2 initValue (I slices) in the compact layout of hevce_common.h  [ref HEVCe.c:763-777] */
-DEVCONST u8 hv_ctxinit[HEVCE_NCTXP] = {
-    139, 141, 157, 184, 184, 63, 153, 138, 138, 111, 141, 94,
-    110, 110, 124, 0, 0, 125, 140, 153, 0, 0, 125, 127, 140, 109, 0, 111, 143, 127, 111, 79,
-    110, 110, 124, 0, 0, 125, 140, 153, 0, 0, 125, 127, 140, 109, 0, 111, 143, 127, 111, 79,
-    91, 171,
-    111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 0,
-    140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152,
-    138, 153, 136, 167, 0, 0 };
+DEVCONST u8 hv_ctxinit[HEVCE_NCTXP] = HEVCE_TAB_CTXINIT;
 DEVCONST signed char hv_ang[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
                                     -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
 DEVCONST short hv_invang[35] = { 0, 0, 256, 315, 390, 482, 630, 910, 1638, 4096, 0, 4096, 1638, 910, 630, 482,
                                  390, 315, 256, 315, 390, 482, 630, 910, 1638, 4096, 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
-DEVCONST u8 hv_lastgrp[32] = { 0,1,2,3,4,4,5,5,6,6,6,6,7,7,7,7,8,8,8,8,8,8,8,8,9,9,9,9,9,9,9,9 };
-DEVCONST u8 hv_lastmin[10] = { 0, 1, 2, 3, 4, 6, 8, 12, 16, 24 };
-DEVCONST u8 hv_sig4[16]    = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };
-DEVCONST u8 hv_sigpos[8]   = { 2, 1, 1, 0, 0, 0, 0, 0 };
+DEVCONST u8 hv_lastgrp[32] = HEVCE_TAB_LASTGRP;
+DEVCONST u8 hv_lastmin[10] = HEVCE_TAB_LASTMIN;
+DEVCONST u8 hv_sig4[16]    = HEVCE_TAB_SIG4;
+DEVCONST u8 hv_sigpos[8]   = HEVCE_TAB_SIGPOS;
 
 /* --------------------------------------------------------------------------------------------- */
 /* LDS image                                                                                       */
@@ -143,11 +151,24 @@ struct alignas(16) HvLds {
     u8    nxn_crec[8][8];
     int   nxn_modes[4];
     /* control */
-    int jobctr, winner, split_sse;
+    int winner, split_sse;
+    int *trace;
     HvWaveScr ws[HV_NWAVES];
 };
 
 struct HvCod { int range; unsigned low; int nbits, nbytes, bufbyte, zeros, nout; };
+
+/* The workgroup's LDS image.  The large routines below are separate (__noinline__) functions: they bind to this
+   symbol directly instead of taking the image by reference, so that every access stays an LDS (ds_*) access. */
+#ifdef HEVCE_EMU
+extern HvLds *emu_lds_ptr;
+#define HV_S (*emu_lds_ptr)
+static inline int hv_uni(int v) { return v; }
+#else
+__shared__ HvLds hv_lds_image;
+#define HV_S hv_lds_image
+static HD int hv_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }     /* value known to be wave-uniform -> SGPR */
+#endif
 
 /* --------------------------------------------------------------------------------------------- */
 /* small helpers                                                                                   */
@@ -338,7 +359,7 @@ static HD void hv_put_remainder(HvCod &c, int v, int k) {                       
     } else {
         int len = k;
         v -= 3 << k;
-        for (; v >= (1 << len); len++) v -= 1 << len;
+        for (; len < 20 && v >= (1 << len); len++) v -= 1 << len;      /* levels are 16-bit: len <= 15; bounded against garbage */
         const int t = 4 + len - k;
         hv_bypass(c, (1 << t) - 2, t);
         hv_bypass(c, v, len);
@@ -347,8 +368,10 @@ static HD void hv_put_remainder(HvCod &c, int v, int k) {                       
 
 /* residual_coding() of one luma TU whose levels are stored in SCAN ORDER at lev[0..n*n)   [ref :1173-1269]
    last / cgsig come from the TU job that produced the levels; slot selects the lane-private staging rows */
-static HD void hv_put_residual(HvLds &S, HvCod &c, u8 *cx, int slot, int n, int lg, int mode,
-                               const short *lev, int last, u64 cgsig) {
+static HDN HvCod hv_put_residual(HvCod c, int slot, int n, int lg, int mode,
+                                 const short *lev, int last, u64 cgsig) {
+    HvLds &S = HV_S;
+    u8 *cx = &S.tctx[0][slot];      /* n, lg, mode are PER-LANE here: lanes of one wave encode different candidates */
     const int kind = hv_scan_kind(n, mode), ncg = n >> 2;
     short *buf = S.cgbuf[slot], *absv = S.absbuf[slot];
     int gy = 0, gx = 0, iy, ix;
@@ -408,12 +431,18 @@ static HD void hv_put_residual(HvLds &S, HvCod &c, u8 *cx, int slot, int n, int 
             }
         }
     }
+    return c;
 }
 
 /* coding_unit() after split_cu_flag: kind 0 = one TU, 1 = four TUs, 2 = NxN   [ref :1272-1340] */
-static HD void hv_put_cu(HvLds &S, HvCod &c, u8 *cx, int slot, int n, int lg, int kind,
-                         const int *mode, const int *left, const int *above,
-                         const short *lev0, int lev_step, const HvTuInfo *info) {
+struct HvModes { int mode[4], left[4], above[4]; };
+static HDN HvCod hv_put_cu(HvCod c, int slot, int n, int lg, int kind, HvModes pm,
+                           const short *lev0, int lev_step) {
+    HvLds &S = HV_S;
+    u8 *cx = &S.tctx[0][slot];
+    const HvTuInfo *info = S.tinfo[slot];
+    const int *mode = pm.mode, *left = pm.left, *above = pm.above;
+    n = hv_uni(n); lg = hv_uni(lg);   /* the CU size is wave-uniform; kind is per-lane */
     if (n == 8) hv_bin(S, c, HV_CX(CX_PART), kind != 2);
     hv_put_modes(S, c, cx, kind == 2 ? 4 : 1, mode, left, above);
     hv_bin(S, c, HV_CX(CX_UVPM), 0);
@@ -422,14 +451,15 @@ static HD void hv_put_cu(HvLds &S, HvCod &c, u8 *cx, int slot, int n, int lg, in
     hv_bin(S, c, HV_CX(CX_UVCBF), 0);
     if (kind == 0) {
         hv_bin(S, c, HV_CX(CX_YCBF + 1), info[0].cbf);
-        if (info[0].cbf) hv_put_residual(S, c, cx, slot, n, lg, mode[0], lev0, info[0].last, info[0].cgsig);
+        if (info[0].cbf) c = hv_put_residual(c, slot, n, lg, mode[0], lev0, info[0].last, info[0].cgsig);
     } else {
         for (int s = 0; s < 4; s++) {
             hv_bin(S, c, HV_CX(CX_YCBF + 0), info[s].cbf);
             if (info[s].cbf)
-                hv_put_residual(S, c, cx, slot, n >> 1, lg - 1, mode[kind == 2 ? s : 0], lev0 + s * lev_step, info[s].last, info[s].cgsig);
+                c = hv_put_residual(c, slot, n >> 1, lg - 1, mode[kind == 2 ? s : 0], lev0 + s * lev_step, info[s].last, info[s].cgsig);
         }
     }
+    return c;
 }
 
 /* --------------------------------------------------------------------------------------------- */
@@ -486,13 +516,17 @@ static HD int hv_smoothed(int n, int m) {
 }
 
 template <int N>
-static HD HvTuOut hv_tu_job(HvLds &S, HvWaveScr &W, int lane, int q,
+static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
                             int ty, int tx,                         /* block origin, CTU-relative            */
                             int cu_y, int cu_x, int cu_n, const u8 *inner,
                             int aL, int aLB, int aA, int aAR,       /* neighbour availability                */
                             int mode,                               /* this slot's mode, or -1 (idle slot)   */
                             short *lev_dst,                         /* N*N levels in scan order (per slot)   */
                             u8 *rec_dst, int rec_stride) {          /* reconstruction (per slot)             */
+    HvLds &S = HV_S;
+    HvWaveScr &W = S.ws[hv_uni(wave)];
+    q = hv_uni(q); ty = hv_uni(ty); tx = hv_uni(tx); cu_y = hv_uni(cu_y); cu_x = hv_uni(cu_x); cu_n = hv_uni(cu_n);
+    aL = hv_uni(aL); aLB = hv_uni(aLB); aA = hv_uni(aA); aAR = hv_uni(aAR);
     constexpr int LG = HvTm<N>::LG, RS = N + 2, BS = 4 * N + 4;
     const int slot = lane / N, j = lane % N;
     const int m = mode < 0 ? 1 : mode;
@@ -707,12 +741,14 @@ struct HvCu { int y, x, n, lg, lvl, L, LB, A, AR; };         /* CTU-relative CU 
 
 /* step 2 jobs: one TU of the CU size  [ref HEVCe.c:1422-1432] */
 template <int N>
-static HD void hv_job_single(HvLds &S, HvWaveScr &W, int lane, int q, const HvCu &cu, int grp, short *glev, u8 *grec) {
+static HDN void hv_job_single(int wave, int lane, int q, HvCu cu, int grp, short *glev, u8 *grec) {
+    HvLds &S = HV_S;
+    grp = hv_uni(grp);
     const int slot = lane / N, j = lane % N;
     const int mode = grp * (64 / N) + slot;
     const bool ok = mode < HEVCE_NMODES;
-    HvTuOut o = hv_tu_job<N>(S, W, lane, q, cu.y, cu.x, cu.y, cu.x, cu.n, nullptr, cu.L, cu.LB, cu.A, cu.AR,
-                             ok ? mode : -1, glev + (ok ? mode : 0) * 1024, grec + (ok ? mode : 0) * 1024, N);
+    HvTuOut o = hv_tu_job<N>(wave, lane, q, cu.y, cu.x, cu.y, cu.x, cu.n, nullptr, cu.L, cu.LB, cu.A, cu.AR,
+                             ok ? mode : -1, glev + (ok ? mode : HV_TL - 1) * 1024, grec + (ok ? mode : HV_TL - 1) * 1024, N);
     if (ok && j == 0) {
         S.tsse[mode] = o.sse;
         S.tinfo[mode][0].cgsig = o.cgsig; S.tinfo[mode][0].last = o.last; S.tinfo[mode][0].cbf = o.cbf;
@@ -720,18 +756,21 @@ static HD void hv_job_single(HvLds &S, HvWaveScr &W, int lane, int q, const HvCu
 }
 /* step 3 jobs: four TUs of half the CU size, each predicted from the previous ones' reconstruction  [ref :1455-1468] */
 template <int H>
-static HD void hv_job_chain(HvLds &S, HvWaveScr &W, int lane, int q, const HvCu &cu, int grp, short *glev, u8 *grec) {
+static HDN void hv_job_chain(int wave, int lane, int q, HvCu cu, int grp, short *glev, u8 *grec) {
+    HvLds &S = HV_S;
+    HvWaveScr &W = S.ws[hv_uni(wave)];
+    grp = hv_uni(grp); cu.n = hv_uni(cu.n); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x);
     const int slot = lane / H, j = lane % H, n = cu.n;
     const int mode = grp * (64 / H) + slot;
     const bool ok = mode < HEVCE_NMODES;
-    const int t = 35 + (ok ? mode : 0);
+    const int t = ok ? 35 + mode : HV_TL - 1;          /* idle slots aim at the unused pad trial */
     u8 *crec = W.crec + slot * n * n;
     int total = 0;
     for (int s = 0; s < 4; s++) {
         int l, lb, a, ar;
         hv_sub_avail(s, cu.L, cu.LB, cu.A, cu.AR, l, lb, a, ar);
         const int oy = (s >> 1) * H, ox = (s & 1) * H;
-        HvTuOut o = hv_tu_job<H>(S, W, lane, q, cu.y + oy, cu.x + ox, cu.y, cu.x, n, crec, l, lb, a, ar,
+        HvTuOut o = hv_tu_job<H>(wave, lane, q, cu.y + oy, cu.x + ox, cu.y, cu.x, n, crec, l, lb, a, ar,
                                  ok ? mode : -1, glev + t * 1024 + s * H * H, crec + oy * n + ox, n);
         total += o.sse;
         if (ok && j == 0) { S.tinfo[t][s].cgsig = o.cgsig; S.tinfo[t][s].last = o.last; S.tinfo[t][s].cbf = o.cbf; }
@@ -744,7 +783,9 @@ static HD void hv_job_chain(HvLds &S, HvWaveScr &W, int lane, int q, const HvCu 
     WAVE_SYNC();
 }
 /* NxN job (8x8 CU only): per 4x4 sub-block choose the mode with a fresh coder and fresh contexts  [ref :1499-1528] */
-static HD void hv_job_nxn(HvLds &S, HvWaveScr &W, int lane, int q, const HvCu &cu) {
+static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
+    HvLds &S = HV_S;
+    q = hv_uni(q); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x);
     const int slot = lane >> 2, j = lane & 3;
     int total = 0;
     for (int s = 0; s < 4; s++) {
@@ -752,13 +793,15 @@ static HD void hv_job_nxn(HvLds &S, HvWaveScr &W, int lane, int q, const HvCu &c
         hv_sub_avail(s, cu.L, cu.LB, cu.A, cu.AR, l, lb, a, ar);
         const int oy = (s >> 1) * 4, ox = (s & 1) * 4;
         for (int g = 0; g < 3; g++) {
+            HV_TRACE(S, 5, s * 100 + g * 10 + 1);
             const int mode = g * 16 + slot;
             const bool ok = mode < HEVCE_NMODES;
-            HvTuOut o = hv_tu_job<4>(S, W, lane, q, cu.y + oy, cu.x + ox, cu.y, cu.x, 8, &S.nxn_crec[0][0], l, lb, a, ar,
+            HvTuOut o = hv_tu_job<4>(wave, lane, q, cu.y + oy, cu.x + ox, cu.y, cu.x, 8, &S.nxn_crec[0][0], l, lb, a, ar,
                                      ok ? mode : -1, S.nxn_lev[ok ? mode : 0], S.nxn_rec[ok ? mode : 0], 4);
             if (ok && j == 0) { S.nxn_sse[mode] = o.sse; S.nxn_last[mode] = o.last; S.nxn_sig[mode] = o.cbf; }
         }
         WAVE_SYNC();
+        HV_TRACE(S, 5, s * 100 + 50);
         /* rate of every candidate: lane = mode  [ref :1505-1519]; residual_coding is written even for an all-zero block */
         int cost = HV_I32MAX, idx = -1;
         if (lane < HEVCE_NMODES) {
@@ -769,15 +812,20 @@ static HD void hv_job_nxn(HvLds &S, HvWaveScr &W, int lane, int q, const HvCu &c
             *HV_CX(CX_ABS) = S.ctx_fresh[CX_ABS];
             HvCod c;
             hv_cod_fresh(c);
-            hv_put_residual(S, c, cx, lane, 4, 2, lane, S.nxn_lev[lane], S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0));
+            HV_TRACE_LANE(S, lane, 1000000 + S.nxn_last[lane] * 1000 + S.nxn_sig[lane]);
+            c = hv_put_residual(c, lane, 4, 2, lane, S.nxn_lev[lane], S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0));
+            HV_TRACE_LANE(S, lane, 2000000 + hv_cod_bits(c));
             cost = hv_rdcost(q, S.nxn_sse[lane], hv_cod_bits(c));
             idx = lane;
         }
+        HV_TRACE(S, 5, s * 100 + 60);
         for (int sft = 1; sft < 64; sft <<= 1) {             /* minimum cost, the LATER mode wins ties  [ref :1521] */
             const int oc = hv_shfl_xor(cost, sft), oi = hv_shfl_xor(idx, sft);
             if (oc < cost || (oc == cost && oi > idx)) { cost = oc; idx = oi; }
         }
         const int w = idx;
+        HV_TRACE(S, 5, s * 100 + 70);
+        HV_TRACE(S, 6, w);
         if (lane < 16) {
             S.nxn_crec[oy + (lane >> 2)][ox + (lane & 3)] = S.nxn_rec[w][lane];
             S.nxn_bestlev[s][lane] = S.nxn_lev[w][lane];
@@ -816,7 +864,7 @@ static HD void hv_commit_bin(HvLds &S, int ctx, int bin) {
 /* --------------------------------------------------------------------------------------------- */
 /* evaluation of one CU: TU jobs -> trial encodes -> arg-min -> commit   [ref HEVCe.c:1350-1560]    */
 /* --------------------------------------------------------------------------------------------- */
-static HD void hv_eval_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HevceRecord *rec) {
+static HD void hv_eval_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HevceRecord *rec, int32_t *dump) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, n = cu.n;
     short *glev = (short *)im.scratch;
     u8 *grec = im.scratch + HV_TL * 1024 * 2;
@@ -828,36 +876,47 @@ static HD void hv_eval_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, Hev
     const int split_inc = (n > S.map_cu[my][mx - 1]) + (n > S.map_cu[my - 1][mx]);
     const int ml = S.map_pm[my][mx - 1], ma = S.map_pm[my - 1][mx];
 
-    if (tid == 0) S.jobctr = 0;
+    HV_TRACE(S, 1, cu.y * 1000 + cu.x * 10 + cu.lvl);
+    HV_TRACE(S, 2, 100);
     for (int k = tid; k < 8 * 8; k += HV_NTHREADS) (&S.nxn_crec[0][0])[k] = 0;
     BLOCK_SYNC();
 
-    /* ---------------- TU jobs, pulled from a queue (longest first) ---------------- */
-    for (;;) {
-        int job = 0;
-        if (lane == 0) job = hv_atomic_inc(&S.jobctr);
-        job = hv_bcast0(job);
-        if (job >= njobs) break;
-        HvWaveScr &W = S.ws[wave];
-        if (n == 8) {
-            if (job == 0) hv_job_nxn(S, W, lane, q, cu);
-            else if (job < 4) hv_job_chain<4>(S, W, lane, q, cu, job - 1, glev, grec);
-            else hv_job_single<8>(S, W, lane, q, cu, job - 4, glev, grec);
-        } else if (n == 16) {
-            if (job < 5) hv_job_chain<8>(S, W, lane, q, cu, job, glev, grec);
-            else if (job < 14) hv_job_single<16>(S, W, lane, q, cu, job - 5, glev, grec);
-            else hv_job_sse(S, lane, cu);
-        } else {
-            if (job < 9) hv_job_chain<16>(S, W, lane, q, cu, job, glev, grec);
-            else if (job < 27) hv_job_single<32>(S, W, lane, q, cu, job - 9, glev, grec);
-            else hv_job_sse(S, lane, cu);
+    /* ---------------- TU jobs: static round-robin over the wavefronts, longest jobs first ----------------
+       (job ids are ordered by cost; rounds alternate direction so that the wave with the longest job gets the
+       fewest extra ones).  Everything controlling this loop is wave-uniform and lives in SGPRs: no lane-dependent
+       control flow may surround the calls, the jobs use wave-level shuffles. */
+    {
+        const int wv = hv_uni(wave), nj = hv_uni(njobs), nn = hv_uni(n);
+#ifdef HEVCE_SERIAL_JOBS
+        for (int job = 0; job < nj && wv == 0; job++) {
+#else
+        for (int round = 0; round * HV_NWAVES < nj; round++) {
+            const int job = round * HV_NWAVES + ((round & 1) ? HV_NWAVES - 1 - wv : wv);
+            if (job >= nj) continue;
+#endif
+            HV_TRACE(S, 3, job);
+            if (nn == 8) {
+                if (job == 0) hv_job_nxn(wave, lane, q, cu);
+                else if (job < 4) hv_job_chain<4>(wave, lane, q, cu, job - 1, glev, grec);
+                else hv_job_single<8>(wave, lane, q, cu, job - 4, glev, grec);
+            } else if (nn == 16) {
+                if (job < 5) hv_job_chain<8>(wave, lane, q, cu, job, glev, grec);
+                else if (job < 14) hv_job_single<16>(wave, lane, q, cu, job - 5, glev, grec);
+                else hv_job_sse(S, lane, cu);
+            } else {
+                if (job < 9) hv_job_chain<16>(wave, lane, q, cu, job, glev, grec);
+                else if (job < 27) hv_job_single<32>(wave, lane, q, cu, job - 9, glev, grec);
+                else hv_job_sse(S, lane, cu);
+            }
         }
     }
+    HV_TRACE(S, 2, 200);
     BLOCK_SYNC();                                               /* the NxN job borrows trial context columns */
     /* trial contexts start from the CU's entry snapshot  [ref :1423-1424] */
     for (int k = tid; k < HEVCE_NCTXP * HV_TL; k += HV_NTHREADS) S.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[cu.lvl][k / HV_TL];
     BLOCK_SYNC();
 
+    HV_TRACE(S, 2, 300);
     /* ---------------- trial encodes: lane = candidate  [ref :1434-1438, 1470-1474, 1540-1544] ---------------- */
     {
         const int t = lane * HV_NWAVES + wave;                  /* spread the candidates over all wavefronts */
@@ -867,19 +926,21 @@ static HD void hv_eval_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, Hev
             const int bits0 = hv_cod_bits(c);
             u8 *cx = &S.tctx[0][t];
             if (n >= 16) hv_bin(S, c, HV_CX(CX_SPLIT_CU + split_inc), 0);
+            HvModes pm;
+            for (int s4 = 0; s4 < 4; s4++) { pm.mode[s4] = 0; pm.left[s4] = 0; pm.above[s4] = 0; }
+            pm.left[0] = ml; pm.above[0] = ma;
             if (t < 35) {
-                hv_put_cu(S, c, cx, t, n, cu.lg, 0, &t, &ml, &ma, glev + t * 1024, 0, S.tinfo[t]);
+                pm.mode[0] = t;
+                c = hv_put_cu(c, t, n, cu.lg, 0, pm, glev + t * 1024, 0);
             } else if (t < 70) {
-                const int m = t - 35;
-                hv_put_cu(S, c, cx, t, n, cu.lg, 1, &m, &ml, &ma, glev + t * 1024, (n >> 1) * (n >> 1), S.tinfo[t]);
+                pm.mode[0] = t - 35;
+                c = hv_put_cu(c, t, n, cu.lg, 1, pm, glev + t * 1024, (n >> 1) * (n >> 1));
             } else {
-                int modes[4], lefts[4], aboves[4];
-                for (int s = 0; s < 4; s++) modes[s] = S.nxn_modes[s];
-                lefts[0] = ml;        aboves[0] = ma;                                   /* [ref :1531-1538] */
-                lefts[1] = modes[0];  aboves[1] = S.map_pm[my - 1][mx + 1];
-                lefts[2] = S.map_pm[my + 1][mx - 1];  aboves[2] = modes[0];
-                lefts[3] = modes[2];  aboves[3] = modes[1];
-                hv_put_cu(S, c, cx, t, 8, 3, 2, modes, lefts, aboves, &S.nxn_bestlev[0][0], 16, S.tinfo[70]);
+                for (int s4 = 0; s4 < 4; s4++) pm.mode[s4] = S.nxn_modes[s4];
+                pm.left[1] = pm.mode[0];  pm.above[1] = S.map_pm[my - 1][mx + 1];                 /* [ref :1531-1538] */
+                pm.left[2] = S.map_pm[my + 1][mx - 1];  pm.above[2] = pm.mode[0];
+                pm.left[3] = pm.mode[2];  pm.above[3] = pm.mode[1];
+                c = hv_put_cu(c, t, 8, 3, 2, pm, &S.nxn_bestlev[0][0], 16);
             }
             S.tcost[t] = hv_rdcost(q, S.tsse[t], hv_cod_bits(c) - bits0);
             hv_cod_store(S.tregs[t], c);
@@ -887,6 +948,23 @@ static HD void hv_eval_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, Hev
     }
     BLOCK_SYNC();
 
+    if (dump && tid < HV_TL) {
+        int32_t *d = dump + 16 * tid;
+        const bool v = tid < ntrials;
+        d[0] = v ? S.tsse[tid] : 0; d[1] = v ? S.tcost[tid] : 0;
+        for (int s4 = 0; s4 < 4; s4++) {
+            d[2 + s4] = v ? S.tinfo[tid][s4].last * 2 + S.tinfo[tid][s4].cbf : 0;
+            d[6 + s4] = v ? (int)(S.tinfo[tid][s4].cgsig & 0xffffffffu) : 0;
+        }
+        d[10] = v ? S.tregs[tid].range : 0; d[11] = v ? (int)S.tregs[tid].low : 0; d[12] = v ? S.tregs[tid].nbits : 0; d[13] = v ? S.tregs[tid].nout : 0;
+        int h = 0;
+        if (v) for (int k = 0; k < HEVCE_NCTX; k++) h = h * 31 + S.tctx[k][tid];
+        d[14] = h;
+        int ck = 0;
+        if (v && tid < 70) for (int k = 0; k < n * n; k++) ck = ck * 131 + glev[tid * 1024 + k];
+        d[15] = ck;
+    }
+    HV_TRACE(S, 2, 400);
     /* ---------------- arg-min in the reference's order, later candidate wins ties ---------------- */
     if (tid == 0) {
         int best = HV_I32MAX, w = -1;
@@ -896,6 +974,7 @@ static HD void hv_eval_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, Hev
     }
     BLOCK_SYNC();
     const int w = S.winner;
+    HV_TRACE(S, 2, 500);
     if (w < 0) return;                                          /* the four sub-CUs stay */
 
     /* ---------------- commit the winner: coder, contexts, reconstruction, maps, record ---------------- */
@@ -962,12 +1041,16 @@ static HD void hv_snapshot(HvLds &S, int lvl, int tid) {
 
 static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int tid = hv_tid(), q = im.qpd6, H = im.H, W = im.W;
+    if (tid == 0) S.trace = im.trace;
+    BLOCK_SYNC();
+    HV_TRACE(S, 0, 1);
     hv_init_tables(S, q, tid);
     BLOCK_SYNC();
     int ctu = 0;
     for (int y0 = 0; y0 < H; y0 += 32) {
         for (int x0 = 0; x0 < W; x0 += 32, ctu++) {
             HevceRecord *rec = (HevceRecord *)(im.records + (size_t)ctu * HEVCE_REC_BYTES);
+            HV_TRACE(S, 0, 1000 + ctu);
             const int L = x0 > 0, A = y0 > 0, AR = A && (x0 + 32 < W);
             /* ---- load the CTU: source samples (edge-replicated), neighbours, maps  [ref :1611-1622] ---- */
             for (int p = tid; p < 1024; p += HV_NTHREADS) {
@@ -1019,8 +1102,9 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     }
                     BLOCK_SYNC();
                 }
+                HV_TRACE(S, 4, step);
                 if (cu.n == 8) { hv_snapshot(S, 0, tid); BLOCK_SYNC(); }
-                hv_eval_cu(S, im, cu, rec);
+                hv_eval_cu(S, im, cu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr);
             }
 
             /* ---- end of CTU: terminate bin, publish reconstruction and line buffers  [ref :1626-1637] ---- */

@@ -1,0 +1,374 @@
+/*
+ * hevce_host.cpp -- C-ABI shim and HIP plumbing around the analysis kernel (include/hevce_mi355x.h).
+ *
+ * One job = a batch of independent images.  All of a job's device memory is one slab in HBM:
+ *   per image: source luma | padded reconstruction | decision records | per-CTU coder state | trial scratch
+ * and one pinned host slab receives the records.  The kernel runs one workgroup per image; the host then
+ * replays the records into .h265 bytes (hevce_writer.cpp), one host thread per image.
+ *
+ * HEVCImageEncoder() keeps the reference's signature (reference src/HEVCe.h:5-12).  The reference cannot fail;
+ * this implementation can (no device): it then returns a negative length and reports on stderr -- it never
+ * falls back to a CPU encoder.
+ */
+#include "hevce_common.h"
+#include "../../include/hevce_mi355x.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+extern "C" int hevce_launch_test_tu(const unsigned char *org, const unsigned char *nbr, int n, int q, int aL, int aLB, int aA, int aAR,
+                                    short *lev, unsigned char *rec, int *info, hipStream_t stream);
+extern "C" int hevce_launch_test_chain(const unsigned char *org, const unsigned char *nbr, int n, int q, int aL, int aLB, int aA, int aAR,
+                                       unsigned char *scratch, int *info, hipStream_t stream);
+extern "C" int hevce_launch_analyse(const HevceImageDesc *d_images, int n, hipStream_t stream);   /* hevce_kernel.hip */
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    fprintf(stderr, "hevce_mi355x: %s\n", buf);
+    return -1;
+}
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+inline int pad32(int v) { return ((v < HEVCE_MAXDIM ? v : HEVCE_MAXDIM) + 31) / 32 * 32; }
+inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+struct Image {
+    int h0, w0, H, W, q, nctu;
+    size_t off_img, off_rcon, off_rec, off_state, off_scratch;   /* into the device slab */
+    size_t hoff_rec, hoff_state;                                 /* into the pinned host slab */
+    const void *ext_img = nullptr;
+    std::vector<uint8_t> stream;
+    int length = 0;
+};
+
+}  // namespace
+
+struct hevce_job {
+    int device = 0, n = 0;
+    std::vector<Image> im;
+    uint8_t *d_slab = nullptr, *h_slab = nullptr;
+    size_t d_bytes = 0, h_bytes = 0;
+    HevceImageDesc *d_desc = nullptr;
+    std::vector<HevceImageDesc> h_desc;
+    bool desc_dirty = true, launched = false;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    float kernel_ms = 0, d2h_ms = 0, writer_ms = 0;
+    int32_t *d_dump = nullptr; size_t dump_ints = 0;   /* diagnostics (HEVCE_DUMP=1) */
+    int32_t *h_trace = nullptr;      /* host-pinned diagnostics, 128 ints per image */
+};
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+const char *hevce_last_error(void) { return g_err.c_str(); }
+const char *hevce_version(void) { return "hevce_mi355x 0.1 (gfx950)"; }
+
+int hevce_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs, const int *qpd6s) {
+    if (n <= 0) { fail("hevce_job_create: n must be positive"); return nullptr; }
+    if (hevce_device_count() <= 0) { fail("no HIP device available: the encoder has no CPU fallback"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fail("hipSetDevice(%d) failed", device); return nullptr; }
+    hevce_job *j = new hevce_job;
+    j->device = device; j->n = n; j->im.resize(n); j->h_desc.resize(n);
+    size_t d = 0, h = 0;
+    for (int i = 0; i < n; i++) {
+        Image &m = j->im[i];
+        if (yszs[i] <= 0 || xszs[i] <= 0 || qpd6s[i] < 0 || qpd6s[i] > 4) { fail("image %d: bad size or qpd6", i); delete j; return nullptr; }
+        m.h0 = yszs[i]; m.w0 = xszs[i]; m.q = qpd6s[i];
+        m.H = pad32(m.h0); m.W = pad32(m.w0); m.nctu = (m.H / 32) * (m.W / 32);
+        m.off_img = d;     d = align256(d + size_t(m.h0) * m.w0);
+        m.off_rcon = d;    d = align256(d + size_t(m.H) * m.W);
+        m.off_rec = d;     d = align256(d + size_t(m.nctu) * HEVCE_REC_BYTES);
+        m.off_state = d;   d = align256(d + size_t(m.nctu) * 32);
+        m.off_scratch = d; d = align256(d + HEVCE_SCRATCH_BYTES);
+        m.hoff_rec = h;    h = align256(h + size_t(m.nctu) * HEVCE_REC_BYTES);
+        m.hoff_state = h;  h = align256(h + size_t(m.nctu) * 32);
+    }
+    j->d_bytes = d; j->h_bytes = h;
+    bool ok = hipMalloc((void **)&j->d_slab, d) == hipSuccess
+           && hipMalloc((void **)&j->d_desc, sizeof(HevceImageDesc) * n) == hipSuccess
+           && hipHostMalloc((void **)&j->h_slab, h, hipHostMallocDefault) == hipSuccess
+           && hipStreamCreateWithFlags(&j->own_stream, hipStreamNonBlocking) == hipSuccess
+           && hipEventCreate(&j->ev0) == hipSuccess && hipEventCreate(&j->ev1) == hipSuccess && hipEventCreate(&j->ev2) == hipSuccess;
+    if (!ok) { fail("hevce_job_create: device allocation failed (%zu bytes HBM, %zu bytes pinned)", d, h); hevce_job_destroy(j); return nullptr; }
+    j->stream = j->own_stream;
+    if (getenv("HEVCE_DUMP")) {
+        for (int i = 0; i < n; i++) j->dump_ints += size_t(j->im[i].nctu) * 21 * HEVCE_TRIALS * 16;
+        if (hipMalloc((void **)&j->d_dump, j->dump_ints * 4) != hipSuccess) j->d_dump = nullptr;
+        else (void)hipMemset(j->d_dump, 0, j->dump_ints * 4);
+    }
+    if (getenv("HEVCE_TRACE")) {
+        if (hipHostMalloc((void **)&j->h_trace, sizeof(int32_t) * 1024 * n, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) memset(j->h_trace, 0, sizeof(int32_t) * 1024 * n);
+        else j->h_trace = nullptr;
+    }
+    return j;
+}
+
+void hevce_job_destroy(hevce_job *j) {
+    if (!j) return;
+    (void)hipSetDevice(j->device);
+    if (j->launched) (void)hipStreamSynchronize(j->stream);
+    if (j->d_slab) (void)hipFree(j->d_slab);
+    if (j->d_desc) (void)hipFree(j->d_desc);
+    if (j->h_slab) (void)hipHostFree(j->h_slab);
+    if (j->h_trace) (void)hipHostFree(j->h_trace);
+    if (j->d_dump) (void)hipFree(j->d_dump);
+    if (j->ev0) (void)hipEventDestroy(j->ev0);
+    if (j->ev1) (void)hipEventDestroy(j->ev1);
+    if (j->ev2) (void)hipEventDestroy(j->ev2);
+    if (j->own_stream) (void)hipStreamDestroy(j->own_stream);
+    delete j;
+}
+
+int hevce_job_upload(hevce_job *j, int i, const unsigned char *img) {
+    if (!j || i < 0 || i >= j->n) return fail("hevce_job_upload: bad arguments");
+    HIPCHK(hipSetDevice(j->device));
+    Image &m = j->im[i];
+    m.ext_img = nullptr; j->desc_dirty = true;
+    HIPCHK(hipMemcpyAsync(j->d_slab + m.off_img, img, size_t(m.h0) * m.w0, hipMemcpyHostToDevice, j->stream));
+    HIPCHK(hipStreamSynchronize(j->stream));
+    return 0;
+}
+
+int hevce_job_set_device_image(hevce_job *j, int i, const void *d_img) {
+    if (!j || i < 0 || i >= j->n) return fail("hevce_job_set_device_image: bad arguments");
+    j->im[i].ext_img = d_img; j->desc_dirty = true;
+    return 0;
+}
+
+int hevce_job_set_stream(hevce_job *j, void *s) {
+    if (!j) return fail("hevce_job_set_stream: null job");
+    j->stream = s ? (hipStream_t)s : j->own_stream;
+    return 0;
+}
+
+int hevce_job_launch(hevce_job *j) {
+    if (!j) return fail("hevce_job_launch: null job");
+    HIPCHK(hipSetDevice(j->device));
+    if (j->desc_dirty) {
+        size_t dump_off = 0;
+        for (int i = 0; i < j->n; i++) {
+            const Image &m = j->im[i];
+            HevceImageDesc &d = j->h_desc[i];
+            d.dump = j->d_dump ? j->d_dump + dump_off : nullptr;
+            dump_off += size_t(m.nctu) * 21 * HEVCE_TRIALS * 16;
+            d.img = m.ext_img ? (const uint8_t *)m.ext_img : j->d_slab + m.off_img;
+            d.rcon = j->d_slab + m.off_rcon;
+            d.records = j->d_slab + m.off_rec;
+            d.ctu_state = (int32_t *)(j->d_slab + m.off_state);
+            d.scratch = j->d_slab + m.off_scratch;
+            d.src_h = m.h0; d.src_w = m.w0; d.H = m.H; d.W = m.W; d.qpd6 = m.q; d.status = 0;
+            d.trace = j->h_trace ? j->h_trace + 1024 * i : nullptr;
+        }
+        HIPCHK(hipMemcpyAsync(j->d_desc, j->h_desc.data(), sizeof(HevceImageDesc) * j->n, hipMemcpyHostToDevice, j->stream));
+        j->desc_dirty = false;
+    }
+    HIPCHK(hipEventRecord(j->ev0, j->stream));
+    if (hevce_launch_analyse(j->d_desc, j->n, j->stream) != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    HIPCHK(hipEventRecord(j->ev1, j->stream));
+    /* records and per-CTU states are contiguous per image; copy image by image into the pinned slab */
+    for (int i = 0; i < j->n; i++) {
+        const Image &m = j->im[i];
+        HIPCHK(hipMemcpyAsync(j->h_slab + m.hoff_rec, j->d_slab + m.off_rec, size_t(m.nctu) * HEVCE_REC_BYTES, hipMemcpyDeviceToHost, j->stream));
+        HIPCHK(hipMemcpyAsync(j->h_slab + m.hoff_state, j->d_slab + m.off_state, size_t(m.nctu) * 32, hipMemcpyDeviceToHost, j->stream));
+    }
+    HIPCHK(hipEventRecord(j->ev2, j->stream));
+    j->launched = true;
+    return 0;
+}
+
+int hevce_job_finish(hevce_job *j) {
+    if (!j || !j->launched) return fail("hevce_job_finish: nothing launched");
+    HIPCHK(hipSetDevice(j->device));
+    HIPCHK(hipEventSynchronize(j->ev2));
+    j->launched = false;
+    HIPCHK(hipEventElapsedTime(&j->kernel_ms, j->ev0, j->ev1));
+    HIPCHK(hipEventElapsedTime(&j->d2h_ms, j->ev1, j->ev2));
+    const auto t0 = std::chrono::steady_clock::now();
+    /* host stream writer: images are independent, one thread each (bounded by the host's cores) */
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("HEVCE_WRITER_THREADS")) hw = (unsigned)atoi(e);
+    int nthreads = (int)(hw ? hw : 1);
+    if (nthreads > j->n) nthreads = j->n;
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= j->n) return;
+            Image &m = j->im[i];
+            m.stream.resize((size_t)hevce_stream_bound(m.h0, m.w0));
+            m.length = hevce_write_stream(m.stream.data(), j->h_slab + m.hoff_rec, m.H, m.W, m.q);
+        }
+    };
+    if (nthreads <= 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++) th.emplace_back(work);
+        for (auto &t : th) t.join();
+    }
+    j->writer_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+/* test hook: TU pipeline of all 35 modes for one n x n block (org 32x32 bytes, nbr 33x65 bytes); outputs are
+   35 x 1024 levels (scan order), 35 x 1024 reconstruction bytes (stride n), 35 x 4 ints (sse, last, cbf, cgsig low) */
+int hevce_test_tu(const unsigned char *org, const unsigned char *nbr, int n, int qpd6, int aL, int aLB, int aA, int aAR,
+                  short *lev, unsigned char *rec, int *info) {
+    if (hevce_device_count() <= 0) return fail("no HIP device available");
+    unsigned char *d = nullptr;
+    const size_t o_org = 0, o_nbr = 1024, o_lev = 4096, o_rec = o_lev + 35 * 2048, o_info = o_rec + 35 * 1024, total = o_info + 35 * 16;
+    HIPCHK(hipMalloc((void **)&d, total));
+    HIPCHK(hipMemset(d, 0, total));
+    HIPCHK(hipMemcpy(d + o_org, org, 1024, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d + o_nbr, nbr, 33 * 65, hipMemcpyHostToDevice));
+    if (hevce_launch_test_tu(d + o_org, d + o_nbr, n, qpd6, aL, aLB, aA, aAR, (short *)(d + o_lev), d + o_rec, (int *)(d + o_info), nullptr) != 0)
+        return fail("test kernel launch failed");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(lev, d + o_lev, 35 * 2048, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rec, d + o_rec, 35 * 1024, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(info, d + o_info, 35 * 16, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(d));
+    return 0;
+}
+/* test hook: TU-split chains of all 35 modes for one n x n CU; outputs: levels 35 x 1024 (four scan-ordered TUs of
+   (n/2)^2 each), reconstruction 35 x 1024 (stride n), info 35 x 16 ints (sse, last[4], cbf[4], cgsig_lo[4]) */
+int hevce_test_chain(const unsigned char *org, const unsigned char *nbr, int n, int qpd6, int aL, int aLB, int aA, int aAR,
+                     short *lev, unsigned char *rec, int *info) {
+    if (hevce_device_count() <= 0) return fail("no HIP device available");
+    unsigned char *d = nullptr;
+    const size_t o_nbr = 1024, o_scr = 4096, o_info = o_scr + HEVCE_SCRATCH_BYTES, total = o_info + 35 * 64;
+    HIPCHK(hipMalloc((void **)&d, total));
+    HIPCHK(hipMemset(d, 0, total));
+    HIPCHK(hipMemcpy(d, org, 1024, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d + o_nbr, nbr, 33 * 65, hipMemcpyHostToDevice));
+    if (hevce_launch_test_chain(d, d + o_nbr, n, qpd6, aL, aLB, aA, aAR, d + o_scr, (int *)(d + o_info), nullptr) != 0)
+        return fail("test kernel launch failed");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(lev, d + o_scr + 35 * 2048, 35 * 2048, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rec, d + o_scr + HEVCE_TRIALS * 2048 + 35 * 1024, 35 * 1024, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(info, d + o_info, 35 * 64, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(d));
+    return 0;
+}
+/* diagnostics: per-CU (sse, cost) of every trial of image 0..n (HEVCE_DUMP=1); returns ints copied */
+long hevce_job_dump(hevce_job *j, int *out, long max_ints) {
+    if (!j || !j->d_dump) return -1;
+    long n = (long)j->dump_ints < max_ints ? (long)j->dump_ints : max_ints;
+    if (hipMemcpy(out, j->d_dump, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+/* diagnostics: 1 when the launched work has completed, 0 while it is running */
+int hevce_job_poll(hevce_job *j) {
+    if (!j || !j->launched) return 1;
+    return hipEventQuery(j->ev2) == hipSuccess ? 1 : 0;
+}
+/* diagnostics: copy image i's first 256 trace ints (HEVCE_TRACE builds + HEVCE_TRACE=1 in the environment) */
+int hevce_job_trace(hevce_job *j, int i, int *out) {
+    if (!j || !j->h_trace || i < 0 || i >= j->n) return -1;
+    memcpy(out, j->h_trace + 1024 * i, sizeof(int32_t) * 256);
+    return 0;
+}
+
+int hevce_job_run(hevce_job *j) {
+    if (hevce_job_launch(j) != 0) return -1;
+    return hevce_job_finish(j);
+}
+
+const unsigned char *hevce_job_stream(hevce_job *j, int i, int *length) {
+    if (!j || i < 0 || i >= j->n) { fail("hevce_job_stream: bad arguments"); return nullptr; }
+    if (length) *length = j->im[i].length;
+    return j->im[i].stream.data();
+}
+
+int hevce_job_padded_size(hevce_job *j, int i, int *ysz, int *xsz) {
+    if (!j || i < 0 || i >= j->n) return fail("hevce_job_padded_size: bad arguments");
+    if (ysz) *ysz = j->im[i].H;
+    if (xsz) *xsz = j->im[i].W;
+    return 0;
+}
+
+int hevce_job_download_rcon(hevce_job *j, int i, unsigned char *dst) {
+    if (!j || i < 0 || i >= j->n) return fail("hevce_job_download_rcon: bad arguments");
+    HIPCHK(hipSetDevice(j->device));
+    const Image &m = j->im[i];
+    HIPCHK(hipMemcpy(dst, j->d_slab + m.off_rcon, size_t(m.H) * m.W, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+void *hevce_job_device_rcon(hevce_job *j, int i) { return (j && i >= 0 && i < j->n) ? j->d_slab + j->im[i].off_rcon : nullptr; }
+void *hevce_job_device_records(hevce_job *j, int i) { return (j && i >= 0 && i < j->n) ? j->d_slab + j->im[i].off_rec : nullptr; }
+
+int hevce_job_download_records(hevce_job *j, int i, unsigned char *records, int *ctu_state) {
+    if (!j || i < 0 || i >= j->n) return fail("hevce_job_download_records: bad arguments");
+    const Image &m = j->im[i];
+    memcpy(records, j->h_slab + m.hoff_rec, size_t(m.nctu) * HEVCE_REC_BYTES);
+    if (ctu_state) memcpy(ctu_state, j->h_slab + m.hoff_state, size_t(m.nctu) * 32);
+    return 0;
+}
+
+int hevce_job_timings(hevce_job *j, float *kernel_ms, float *d2h_ms, float *writer_ms) {
+    if (!j) return fail("hevce_job_timings: null job");
+    if (kernel_ms) *kernel_ms = j->kernel_ms;
+    if (d2h_ms) *d2h_ms = j->d2h_ms;
+    if (writer_ms) *writer_ms = j->writer_ms;
+    return 0;
+}
+
+/* ---- the reference's entry point and its batch form --------------------------------------------------- */
+int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs,
+                          unsigned char *const *img_rcons, int *yszs, int *xszs, const int *qpd6s, int *lengths) {
+    int device = 0;
+    if (const char *e = getenv("HEVCE_DEVICE")) device = atoi(e);
+    hevce_job *j = hevce_job_create(device, n, yszs, xszs, qpd6s);
+    if (!j) return -1;
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; i++) rc = hevce_job_upload(j, i, imgs[i]);
+    if (rc == 0) rc = hevce_job_run(j);
+    for (int i = 0; i < n && rc == 0; i++) {
+        const Image &m = j->im[i];
+        memcpy(pbuffers[i], m.stream.data(), (size_t)m.length);
+        if (lengths) lengths[i] = m.length;
+        rc = hevce_job_download_rcon(j, i, img_rcons[i]);
+        yszs[i] = m.H; xszs[i] = m.W;
+    }
+    hevce_job_destroy(j);
+    return rc;
+}
+
+__attribute__((visibility("default"))) int HEVCImageEncoder(unsigned char *pbuffer, const unsigned char *img, unsigned char *img_rcon,
+                     int *ysz, int *xsz, const int qpd6) {
+    int len = 0;
+    unsigned char *pb[1] = { pbuffer };
+    const unsigned char *im[1] = { img };
+    unsigned char *rc[1] = { img_rcon };
+    const int q[1] = { qpd6 };
+    if (HEVCImageEncoderBatch(1, pb, im, rc, ysz, xsz, q, &len) != 0) return -1;
+    return len;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

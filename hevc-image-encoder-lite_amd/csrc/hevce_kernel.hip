@@ -1,0 +1,111 @@
+/*
+ * hevce_kernel.hip -- gfx950 entry points of the analysis path.  One 512-thread workgroup per image of the batch.
+ */
+#include "hevce_device.h"
+
+extern "C" __global__ void __launch_bounds__(HV_NTHREADS, 2)
+hevce_analyse_kernel(const HevceImageDesc *__restrict__ images, int nimages) {
+    const int b = blockIdx.x;
+    if (b >= nimages) return;
+    const HevceImageDesc im = images[b];
+    hv_analyse_image(HV_S, im);
+}
+
+/* host-side launcher used by hevce_host.cpp: grid = images of the batch */
+extern "C" int hevce_launch_analyse(const HevceImageDesc *d_images, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(hevce_analyse_kernel, dim3((unsigned)n), dim3(HV_NTHREADS), 0, stream, d_images, n);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+/* ---- function-level test hook: the TU pipeline (prediction -> T -> Q -> Q^-1 -> T^-1 -> reconstruction) for all 35
+   modes of ONE n x n block at the CTU origin, from an explicit 33x65 neighbourhood.  One wavefront. ------------------- */
+extern "C" __global__ void __launch_bounds__(64, 1)
+hevce_test_tu_kernel(const unsigned char *org /*32x32*/, const unsigned char *nbr /*33x65: row 0 = y-1, col 0 = x-1*/,
+                     int n, int q, int aL, int aLB, int aA, int aAR,
+                     short *lev /*35 x 1024, scan order*/, unsigned char *rec /*35 x 1024*/, int *info /*35 x 4: sse,last,cbf,cgsig_lo*/) {
+    HvLds &S = HV_S;
+    const int tid = (int)threadIdx.x;
+    hv_init_tables(S, q, tid);
+    if (tid < 64) { S.lps4[tid] = hv_lps4[tid]; }
+    for (int p = tid; p < 1024; p += 64) S.org[p >> 5][p & 31] = org[p];
+    for (int p = tid; p < 33 * 65; p += 64) S.rec[p / 65][HV_RX - 1 + p % 65] = nbr[p];
+    if (tid == 0) S.trace = nullptr;
+    __syncthreads();
+    /* the single-wave block has no thread 64/128/300: build the scan tables and contexts here */
+    if (tid == 0) {
+        int k = 0;
+        for (int d = 0; d <= 6; d++)
+            for (int y = (d < 4 ? d : 3); y >= 0 && d - y < 4; y--) { S.d4pos[k] = (u8)((y << 2) | (d - y)); S.d4idx[(y << 2) | (d - y)] = (u8)k; k++; }
+        for (int t = 0; t < 3; t++) {
+            const int ng = 2 << t;
+            k = 0;
+            for (int d = 0; d <= 2 * (ng - 1); d++)
+                for (int y = (d < ng ? d : ng - 1); y >= 0 && d - y < ng; y--) { S.cgpos[t][k] = (u8)((y << 3) | (d - y)); S.cgidx[t][y * ng + (d - y)] = (u8)k; k++; }
+        }
+    }
+    __syncthreads();
+    const int per = 64 / n;
+    for (int grp = 0; grp * per < HEVCE_NMODES; grp++) {
+        const int mode = grp * per + tid / n;
+        const bool ok = mode < HEVCE_NMODES;
+        HvTuOut o;
+        short *ld = lev + (ok ? mode : 0) * 1024;
+        unsigned char *rd = rec + (ok ? mode : 0) * 1024;
+        if (n == 4)       o = hv_tu_job<4>(0, tid, q, 0, 0, 0, 0, n, nullptr, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
+        else if (n == 8)  o = hv_tu_job<8>(0, tid, q, 0, 0, 0, 0, n, nullptr, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
+        else if (n == 16) o = hv_tu_job<16>(0, tid, q, 0, 0, 0, 0, n, nullptr, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
+        else              o = hv_tu_job<32>(0, tid, q, 0, 0, 0, 0, n, nullptr, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
+        if (ok && tid % n == 0) { info[mode * 4] = o.sse; info[mode * 4 + 1] = o.last; info[mode * 4 + 2] = o.cbf; info[mode * 4 + 3] = (int)(o.cgsig & 0xffffffffu); }
+    }
+}
+
+extern "C" int hevce_launch_test_tu(const unsigned char *org, const unsigned char *nbr, int n, int q, int aL, int aLB, int aA, int aAR,
+                                    short *lev, unsigned char *rec, int *info, hipStream_t stream) {
+    hipLaunchKernelGGL(hevce_test_tu_kernel, dim3(1), dim3(64), 0, stream, org, nbr, n, q, aL, aLB, aA, aAR, lev, rec, info);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+/* ---- function-level test hook: the TU-split chains (four TUs of n/2, each predicted from the previous ones'
+   reconstruction) of all 35 modes for ONE n x n CU at the CTU origin.  One wavefront runs the chain jobs in turn. --- */
+extern "C" __global__ void __launch_bounds__(64, 1)
+hevce_test_chain_kernel(const unsigned char *org, const unsigned char *nbr, int n, int q, int aL, int aLB, int aA, int aAR,
+                        unsigned char *scratch /*HEVCE_SCRATCH_BYTES*/, int *info /*35 x 16*/) {
+    HvLds &S = HV_S;
+    const int tid = (int)threadIdx.x;
+    hv_init_tables(S, q, tid);
+    for (int p = tid; p < 1024; p += 64) S.org[p >> 5][p & 31] = org[p];
+    for (int p = tid; p < 33 * 65; p += 64) S.rec[p / 65][HV_RX - 1 + p % 65] = nbr[p];
+    if (tid == 0) {
+        S.trace = nullptr;
+        int k = 0;
+        for (int d = 0; d <= 6; d++)
+            for (int y = (d < 4 ? d : 3); y >= 0 && d - y < 4; y--) { S.d4pos[k] = (u8)((y << 2) | (d - y)); S.d4idx[(y << 2) | (d - y)] = (u8)k; k++; }
+        for (int t = 0; t < 3; t++) {
+            const int ng = 2 << t;
+            k = 0;
+            for (int d = 0; d <= 2 * (ng - 1); d++)
+                for (int y = (d < ng ? d : ng - 1); y >= 0 && d - y < ng; y--) { S.cgpos[t][k] = (u8)((y << 3) | (d - y)); S.cgidx[t][y * ng + (d - y)] = (u8)k; k++; }
+        }
+    }
+    __syncthreads();
+    short *glev = (short *)scratch;
+    u8 *grec = scratch + HV_TL * 1024 * 2;
+    HvCu cu = { 0, 0, n, n == 8 ? 3 : n == 16 ? 4 : 5, n == 8 ? 0 : n == 16 ? 1 : 2, aL, aLB, aA, aAR };
+    const int per = 64 / (n / 2);
+    for (int grp = 0; grp * per < HEVCE_NMODES; grp++) {
+        if (n == 8) hv_job_chain<4>(0, tid, q, cu, grp, glev, grec);
+        else if (n == 16) hv_job_chain<8>(0, tid, q, cu, grp, glev, grec);
+        else hv_job_chain<16>(0, tid, q, cu, grp, glev, grec);
+    }
+    __syncthreads();
+    for (int m = tid; m < HEVCE_NMODES; m += 64) {
+        int *d = info + m * 16;
+        d[0] = S.tsse[35 + m];
+        for (int s = 0; s < 4; s++) { d[1 + s] = S.tinfo[35 + m][s].last; d[5 + s] = S.tinfo[35 + m][s].cbf; d[9 + s] = (int)(S.tinfo[35 + m][s].cgsig & 0xffffffffu); }
+    }
+}
+extern "C" int hevce_launch_test_chain(const unsigned char *org, const unsigned char *nbr, int n, int q, int aL, int aLB, int aA, int aAR,
+                                       unsigned char *scratch, int *info, hipStream_t stream) {
+    hipLaunchKernelGGL(hevce_test_chain_kernel, dim3(1), dim3(64), 0, stream, org, nbr, n, q, aL, aLB, aA, aAR, scratch, info);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -1,0 +1,88 @@
+/*
+ * hevce_mi355x.h -- C ABI of the MI355X-native HEVC intra still-picture encoder (libhevce_mi355x.so).
+ *
+ * Drop-in boundary: HEVCImageEncoder() has the signature and semantics of the reference's only exported
+ * function (reference src/HEVCe.h:5-12, defined src/HEVCe.c:1570-1647, called from src/HEVCeMain.c:197).
+ * Everything else is additive: a batch entry point (one image = one serial chain = one workgroup, so
+ * only batches fill a GPU) and a job object that keeps images, reconstructions and decision records
+ * resident in HBM.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * There is NO CPU fallback: if no HIP device is usable the calls fail (return < 0, message on stderr and
+ * in hevce_last_error()).
+ */
+#ifndef HEVCE_MI355X_H
+#define HEVCE_MI355X_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- the reference interface (replaces reference src/HEVCe.h:5-12) ---------------------------------------
+ * pbuffer  : out, HEVC stream (VPS+SPS+PPS+slice).  Caller-owned, no capacity argument (as in the reference);
+ *            hevce_stream_bound() gives a safe size.
+ * img      : in, 8-bit luma, *ysz rows of *xsz samples (stride *xsz).
+ * img_rcon : out, reconstruction of the PADDED picture: ceil32(*ysz) rows of ceil32(*xsz) samples.
+ * ysz,xsz  : in/out, replaced by the padded size; inputs above 8192 are cropped like the reference does.
+ * qpd6     : 0..4 (QP = 6*qpd6+4).
+ * returns  : stream length in bytes (> 0), or a negative value if the GPU path is unavailable / failed. */
+int HEVCImageEncoder(unsigned char *pbuffer, const unsigned char *img, unsigned char *img_rcon,
+                     int *ysz, int *xsz, const int qpd6);
+
+/* ---- additive: n independent images in one launch (arrays of the six arguments + per-image lengths) ---- */
+int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs,
+                          unsigned char *const *img_rcons, int *yszs, int *xszs, const int *qpd6s, int *lengths);
+
+/* upper bound of the stream size for a picture of the given (unpadded) size */
+long hevce_stream_bound(int ysz, int xsz);
+
+/* ---- device-resident jobs (bench / batch front-ends) -------------------------------------------------- */
+typedef struct hevce_job hevce_job;
+
+/* allocate device + pinned host buffers for n images of the given sizes on HIP device `device` */
+hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs, const int *qpd6s);
+void       hevce_job_destroy(hevce_job *job);
+/* copy image i from host memory (stride = xszs[i]) into the job's HBM buffer */
+int  hevce_job_upload(hevce_job *job, int i, const unsigned char *img);
+/* use an image that already lives in HBM (e.g. a torch tensor's data_ptr); the job does not own it */
+int  hevce_job_set_device_image(hevce_job *job, int i, const void *d_img);
+/* run on this hipStream_t (NULL = the job's own stream) */
+int  hevce_job_set_stream(hevce_job *job, void *hip_stream);
+/* analysis kernel over all images + D2H of the decision records + host stream writer.  0 on success */
+int  hevce_job_run(hevce_job *job);
+/* the two halves of hevce_job_run, for callers that overlap them */
+int  hevce_job_launch(hevce_job *job);          /* enqueue kernel + async D2H of records */
+int  hevce_job_finish(hevce_job *job);          /* wait, then write the streams on the host */
+/* results */
+const unsigned char *hevce_job_stream(hevce_job *job, int i, int *length);
+int  hevce_job_padded_size(hevce_job *job, int i, int *ysz, int *xsz);
+int  hevce_job_download_rcon(hevce_job *job, int i, unsigned char *img_rcon);
+void *hevce_job_device_rcon(hevce_job *job, int i);
+void *hevce_job_device_records(hevce_job *job, int i);
+int  hevce_job_download_records(hevce_job *job, int i, unsigned char *records, int *ctu_state /* 8 ints per CTU, may be NULL */);
+/* timings of the last run, milliseconds: kernel (HIP events on the launch stream), D2H wait, host writer */
+int  hevce_job_timings(hevce_job *job, float *kernel_ms, float *d2h_ms, float *writer_ms);
+
+/* diagnostics and function-level test hooks */
+int  hevce_test_tu(const unsigned char *org32x32, const unsigned char *nbr33x65, int n, int qpd6, int aL, int aLB, int aA, int aAR,
+                   short *lev35x1024, unsigned char *rec35x1024, int *info35x4);
+int  hevce_job_poll(hevce_job *job);                      /* 1 = launched work finished, 0 = still running */
+long hevce_job_dump(hevce_job *job, int *out, long max_ints); /* per-trial (sse, cost) of every CU evaluation (HEVCE_DUMP=1) */
+int  hevce_job_trace(hevce_job *job, int i, int *out256);  /* checkpoints of a -DHEVCE_TRACE build (HEVCE_TRACE=1) */
+
+int  hevce_test_chain(const unsigned char *org32x32, const unsigned char *nbr33x65, int n, int qpd6, int aL, int aLB, int aA, int aAR,
+                      short *lev35x1024, unsigned char *rec35x1024, int *info35x16);
+
+/* ---- host-side pieces, usable without a GPU ---------------------------------------------------------------- */
+/* decision records (hevce_record_bytes() per CTU, raster order) -> complete .h265; returns its length
+   (replaces reference src/HEVCe.c:625-691 header writer, :840-856 finish, and the byte-emitting half of :797-933) */
+int  hevce_write_stream(unsigned char *out, const unsigned char *records, int ysz_padded, int xsz_padded, int qpd6);
+int  hevce_write_header(unsigned char *out, int qpd6, int ysz_padded, int xsz_padded);
+int  hevce_record_bytes(void);
+int  hevce_device_count(void);                  /* HIP devices visible; <= 0 means the GPU path cannot run */
+const char *hevce_last_error(void);
+const char *hevce_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

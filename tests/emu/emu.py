@@ -1,0 +1,43 @@
+"""TEST INFRASTRUCTURE: ctypes access to the CPU fiber emulation of the device analysis code."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "hevc-image-encoder-lite_amd", "csrc")
+_u8p = C.POINTER(C.c_uint8)
+_lib = None
+
+
+def build():
+    so = os.path.join(HERE, "libhevce_emu.so")
+    deps = [os.path.join(HERE, "emu_main.cpp"), os.path.join(HERE, "emu_rt.h"),
+            os.path.join(CSRC, "hevce_device.h"), os.path.join(CSRC, "hevce_common.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + HERE,
+                               "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", so, deps[0]])
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def analyse(img, q, want_dump=False):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    H, W = (min(h, 8192) + 31) // 32 * 32, (min(w, 8192) + 31) // 32 * 32
+    nctu = (H // 32) * (W // 32)
+    rec = np.zeros((nctu, 2176), np.uint8)
+    st = np.zeros((nctu, 8), np.int32)
+    rcon = np.zeros((H, W), np.uint8)
+    dump = np.zeros((nctu, 21, 72, 16), np.int32) if want_dump else None
+    rc = lib().emu_analyse(img.ctypes.data_as(_u8p), h, w, q, rcon.ctypes.data_as(_u8p), rec.ctypes.data_as(_u8p),
+                           st.ctypes.data_as(C.POINTER(C.c_int32)), dump.ctypes.data_as(C.POINTER(C.c_int32)) if want_dump else None)
+    assert rc == 0, "emulator deadlock"
+    return (rec, rcon, st, dump) if want_dump else (rec, rcon, st)

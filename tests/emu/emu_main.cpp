@@ -5,6 +5,7 @@
 #include <vector>
 
 int emu_cur = 0;
+HvLds *emu_lds_ptr = nullptr;
 int emu_stage[8][64];
 
 namespace {
@@ -62,10 +63,11 @@ void emu_block_sync(void) {
 }
 
 extern "C" __attribute__((visibility("default")))
-int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, uint8_t *records, int32_t *ctu_state) {
+int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, uint8_t *records, int32_t *ctu_state, int32_t *dump) {
     HevceImageDesc im;
     memset(&im, 0, sizeof im);
     im.img = img; im.rcon = rcon; im.records = records; im.ctu_state = ctu_state;
+    im.dump = dump;
     im.src_h = src_h; im.src_w = src_w; im.qpd6 = q;
     im.H = ((src_h < HEVCE_MAXDIM ? src_h : HEVCE_MAXDIM) + 31) / 32 * 32;
     im.W = ((src_w < HEVCE_MAXDIM ? src_w : HEVCE_MAXDIM) + 31) / 32 * 32;
@@ -73,11 +75,11 @@ int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, 
     im.scratch = scratch.data();
     HvLds *lds = (HvLds *)aligned_alloc(64, (sizeof(HvLds) + 63) / 64 * 64);
     memset(lds, 0xAB, sizeof(HvLds));                     /* LDS is not zero-initialised on the GPU either */
-    g_lds = lds; g_im = &im;
+    g_lds = lds; g_im = &im; emu_lds_ptr = lds;
     memset(wave_wait, 0, sizeof wave_wait); block_wait = 0; ndone = 0;
     for (int i = 0; i < NT; i++) {
         fib[i].stack = (char *)aligned_alloc(64, STACK);
-        void **sp = (void **)(fib[i].stack + STACK - 64);
+        void **sp = (void **)(fib[i].stack + STACK - 64 - 8);   /* at fiber_entry's first instruction rsp must be 8 mod 16 */
         *--sp = (void *)fiber_entry;                      /* return address for emu_switch's ret */
         for (int k = 0; k < 6; k++) *--sp = 0;            /* rbp rbx r12..r15 */
         fib[i].sp = sp; fib[i].st = RUN;

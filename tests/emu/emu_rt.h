@@ -11,8 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define HD  static inline
-#define HDN static
+#define HD  inline
+#define HDN
 #define DEVCONST static const
 
 void emu_wave_sync(void);
@@ -23,8 +23,8 @@ extern int  emu_stage[8][64];        /* shuffle staging, per wave */
 #define WAVE_SYNC()  emu_wave_sync()
 #define BLOCK_SYNC() emu_block_sync()
 
-HD int hv_tid() { return emu_cur; }
-HD int hv_shfl_xor(int v, int m) {
+static inline int hv_tid() { return emu_cur; }
+static inline int hv_shfl_xor(int v, int m) {
     const int w = emu_cur >> 6, l = emu_cur & 63;
     emu_stage[w][l] = v;
     emu_wave_sync();
@@ -32,7 +32,7 @@ HD int hv_shfl_xor(int v, int m) {
     emu_wave_sync();
     return r;
 }
-HD int hv_bcast0(int v) {
+static inline int hv_bcast0(int v) {
     const int w = emu_cur >> 6, l = emu_cur & 63;
     if (l == 0) emu_stage[w][0] = v;
     emu_wave_sync();
@@ -40,9 +40,9 @@ HD int hv_bcast0(int v) {
     emu_wave_sync();
     return r;
 }
-HD int hv_atomic_inc(int *p) { return (*p)++; }
-HD int hv_mul24(int a, int b) {
+static inline int hv_atomic_inc(int *p) { return (*p)++; }
+static inline int hv_mul24(int a, int b) {
     if (a < -(1 << 23) || a >= (1 << 23) || b < -(1 << 23) || b >= (1 << 23)) { fprintf(stderr, "emu: mul24 operand out of range %d %d\n", a, b); abort(); }
     return a * b;
 }
-HD int hv_clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
+static inline int hv_clz(unsigned v) { return v ? __builtin_clz(v) : 32; }

@@ -1,0 +1,59 @@
+"""CPU: the product's C-ABI library loads, exports every symbol declared in include/hevce_mi355x.h, its host stream
+writer reproduces the golden streams from golden decision records, and the GPU entry points fail loudly (no CPU
+fallback) when there is no device."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_case, small_cases
+
+
+def test_exports_match_header(hevce):
+    hdr = open(os.path.join(ROOT, "include", "hevce_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(HEVCImageEncoder(?:Batch)?|hevce_[a-z_0-9]+)\s*\(", hdr))
+    declared.discard("hevce_job")
+    out = subprocess.check_output(["nm", "-D", "--defined-only", hevce.LIB_PATH]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert declared <= exported, declared - exported
+    assert {e for e in exported if not (e.startswith("hevce_") or e.startswith("HEVCImageEncoder"))} == set()
+    for name in declared:
+        getattr(hevce.lib(), name)
+
+
+@pytest.mark.parametrize("path", small_cases(), ids=lambda p: os.path.basename(p)[6:-4])
+def test_host_writer_replays_golden_records(hevce, path):
+    c = load_case(path)
+    H, W = c["rcon"].shape
+    assert hevce.write_stream(c["records"], H, W, c["q"]) == c["stream"]
+
+
+def test_header_bytes(hevce):
+    c = load_case(small_cases()[0])
+    H, W = c["rcon"].shape
+    h = hevce.write_header(c["q"], H, W)
+    assert c["stream"].startswith(h)
+    assert len(hevce.write_header(2, 512, 768)) == 79          # 79 bytes at 768x512
+    assert hevce.lib().hevce_record_bytes() == 2176
+
+
+def test_no_cpu_fallback(hevce):
+    if hevce.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(hevce.HevceError):
+        hevce.HEVCImageEncoder(np.zeros((32, 32), np.uint8), 2)
+    with pytest.raises(hevce.HevceError):
+        hevce.Job([(32, 32)], 2)
+
+
+def test_product_does_not_reference_oracle():
+    """the shipped sources never include, link or call anything under oracle/"""
+    pkg = os.path.join(ROOT, "hevc-image-encoder-lite_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".h", ".hip", ".cpp", ".c", ".py", "Makefile", ".map")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle/" not in txt and "hevce_oracle" not in txt and "orc_" not in txt, os.path.join(dp, f)
