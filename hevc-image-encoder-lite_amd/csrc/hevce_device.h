@@ -18,6 +18,8 @@
 
 #ifdef HEVCE_EMU
 #include "emu_rt.h"
+#define HV_GLOBAL
+#define HV_KEEP(x) do { } while (0)
 #else
 #include <hip/hip_runtime.h>
 #define HD  __device__ __forceinline__
@@ -40,10 +42,14 @@
 #else
 #define BLOCK_SYNC() __syncthreads()
 #endif
+#define HV_KEEP(x) asm volatile("" : "+v"(x))          /* pins the first use of a prefetched value to this point */
+#define HV_GLOBAL __attribute__((address_space(1)))    /* pointer known to address HBM: global_load instead of flat_load */
 static HD int  hv_tid() { return (int)threadIdx.x; }
 static HD int  hv_shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 static HD int  hv_bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }   /* lane 0's value, wave-uniform (SGPR) */
 static HD int  hv_atomic_inc(int *p) { return atomicAdd(p, 1); }
+static HD void hv_atomic_min(int *p, int v) { atomicMin(p, v); }
+static HD int  hv_peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 static HD int  hv_mul24(int a, int b) { return __mul24(a, b); }
 static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v == 0 */
 #endif
@@ -56,6 +62,19 @@ static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v
 #else
 #define HV_TRACE(S, slotno, code) do { } while (0)
 #define HV_TRACE_LANE(S, idx, code) do { } while (0)
+#endif
+
+/* diagnostics: -DHEVCE_PROF accumulates shader-clock cycles per phase and CU size (thread 0, after the barriers) */
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+#define HV_PROF_T0()  unsigned long long pt_ = __builtin_amdgcn_s_memtime()
+#define HV_PROF2_T0() unsigned long long p2_ = __builtin_amdgcn_s_memtime()
+#define HV_PROF2(S, ph) do { if ((hv_tid() & 63) == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof2[ph] += n_ - p2_; p2_ = n_; } } while (0)
+#define HV_PROF(S, lvl, ph) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof[lvl][ph] += n_ - pt_; pt_ = n_; } } while (0)
+#else
+#define HV_PROF_T0() do { } while (0)
+#define HV_PROF2_T0() do { } while (0)
+#define HV_PROF2(S, ph) do { } while (0)
+#define HV_PROF(S, lvl, ph) do { } while (0)
 #endif
 
 #define HV_NTHREADS 512
@@ -141,17 +160,23 @@ struct alignas(16) HvLds {
     u8  tctx[HEVCE_NCTXP][HV_TL];
     HevceCoderRegs tregs[HV_TL];
     int tcost[HV_TL], tsse[HV_TL];
+    u16 shdr[HV_TL][HEVCE_TOKEN_SLOTS + 2];                 /* slot headers, then (offset | g1 << 15) after linking */
+    int tlen[HV_TL];                                        /* tokens in each candidate's linked stream */
+    int best_cost;                                          /* lowest cost of a COMPLETED candidate of this CU (pruning bound) */
+    u8  tdead[HV_TL];                                       /* candidate abandoned: its partial cost already exceeded best_cost */
     HvTuInfo tinfo[HV_TL][4];
-    short cgbuf[HV_TL][16], absbuf[HV_TL][16];
     /* NxN sub-search */
     short nxn_lev[35][16];
     u8    nxn_rec[35][16];
     int   nxn_sse[35], nxn_last[35], nxn_sig[35];
     short nxn_bestlev[4][16];
+    alignas(16) u16 nxn_tok[35][144];                                 /* per candidate: its token stream (header + one group), 16-byte rows */
     u8    nxn_crec[8][8];
     int   nxn_modes[4];
     /* control */
     int winner, split_sse;
+    unsigned long long prof[3][8];
+    unsigned long long prof2[8];                            /* HEVCE_PROF: inside the NxN job (tu jobs, tokenise, engine, select) */
     int *trace;
     HvWaveScr ws[HV_NWAVES];
 };
@@ -249,6 +274,28 @@ static HD void hv_cod_carry(HvCod &c) {                                         
         }
     }
 }
+/* same state machine with the common case (one finished byte, no pending 0xff run) straight-line */
+static HD void hv_cod_carry_fast(HvCod &c) {
+    if (c.nbits < 12) {
+        const int lead = (int)(c.low >> (24 - c.nbits));
+        c.nbits += 8;
+        c.low &= 0xffffffffu >> c.nbits;
+        if (c.nbytes > 1 && lead != 0xff) {                  /* rare: flush a run of buffered 0xff bytes */
+            const int carry = lead >> 8, fill = (0xff + carry) & 0xff;
+            hv_cod_out(c, c.bufbyte + carry);
+            c.bufbyte = lead & 0xff;
+            for (; c.nbytes > 1; c.nbytes--) hv_cod_out(c, fill);
+        } else {
+            const int isff = lead == 0xff, emit = !isff && c.nbytes > 0;
+            const int byte = (c.bufbyte + (lead >> 8)) & 0xff;
+            const int epb = emit && c.zeros >= 2 && byte <= 3;
+            c.nout += emit + epb;
+            c.zeros = emit ? (byte ? 0 : (epb ? 1 : c.zeros + 1)) : c.zeros;
+            c.nbytes = isff ? c.nbytes + 1 : 1;
+            c.bufbyte = isff ? c.bufbyte : (emit ? (lead & 0xff) : lead);     /* first byte ever: stored unmasked, as the reference does */
+        }
+    }
+}
 /* context-coded bin; cx points at this trial's context byte  [ref :914-933] */
 static HD void hv_bin(const HvLds &S, HvCod &c, u8 *cx, int bin) {
     const int v = *cx, st = v >> 1, mps = v & 1;
@@ -284,9 +331,44 @@ static HD void hv_terminate(HvCod &c, int bin) {                                
 }
 
 /* --------------------------------------------------------------------------------------------- */
-/* syntax elements of a trial; cx = &S.tctx[0][slot], contexts are HV_TL apart                      */
+/* Syntax = binarisation + arithmetic engine, separated.                                            */
+/*                                                                                                  */
+/* A candidate's bins are first written as 16-bit TOKENS into fixed-size SLOTS (one slot per CU      */
+/* header, per TU header and per 4x4 coefficient group, in coding order); the binarisation of a slot */
+/* needs only that group's levels and a few TU-level facts, so slots are produced data-parallel.     */
+/* The arithmetic engine is then a tight loop in which every lane consumes ITS candidate's token      */
+/* stream: all lanes run the same instructions (no per-candidate control flow), which is what a      */
+/* 64-wide wavefront needs.  The reference interleaves both (HEVCe.c:943-1340 call CABACputBin*).    */
+/*                                                                                                  */
+/*   token, context bin : bit15=0, bits0-6 context index, bit7 bin value,                            */
+/*                        bit13 / bit14: add 4 / 1 to the index when the previous coded group had a   */
+/*                        level > 1 among its first eight (greater1 / greater2 context sets)          */
+/*   token, bypass chunk: bit15=1, bits8-11 length (1..8), bits0-7 bins  -- one token per <=8-bit      */
+/*                        chunk, exactly the chunks reference CABACputBins makes (HEVCe.c:899-911)    */
+/*   slot header (word 0): bits0-7 token count, bit8 group had non-zero levels, bit9 its greater1     */
+/*                        outcome (c1 == 0), bit10 start of a transform block (resets that memory)    */
 /* --------------------------------------------------------------------------------------------- */
-#define HV_CX(i) (cx + (i) * HV_TL)
+#define HV_SLOT        HEVCE_TOKEN_SLOT_WORDS /* 16-bit words per slot: header + up to 127 tokens (a group needs <= 109) */
+#define HV_SLOTS_TRIAL HEVCE_TOKEN_SLOTS                     /* CU header + at most 4 x (1 + 16) or 1 + 64 block/group slots            */
+#define HV_TOK_BYP     0x8000
+#define HV_TOK_G4      0x2000
+#define HV_TOK_G1      0x4000
+#define HV_HDR_NZ      0x100
+#define HV_HDR_G1      0x200
+#define HV_HDR_RESET   0x400
+
+struct HvTokW { u16 *p; int n; };
+#define HV_SLOT_TOK0 8                      /* tokens start 16 bytes into the slot so that chunks of 8 load as one dwordx4 */
+static HD void hv_tok_ctx(HvTokW &w, int ctx, int bin) { w.p[HV_SLOT_TOK0 + w.n] = (u16)(ctx | (bin ? 0x80 : 0)); w.n++; }
+static HD void hv_tok_byp(HvTokW &w, int bins, int len) {                                                 /* [ref :899-911] */
+    bins &= (1 << len) - 1;
+    while (len > 0) {
+        const int n = hv_min(len, 8);
+        len -= n;
+        w.p[HV_SLOT_TOK0 + w.n] = (u16)(HV_TOK_BYP | (n << 8) | ((bins >> len) & ((1 << n) - 1)));
+        w.n++;
+    }
+}
 
 static HD void hv_mpm(int left, int above, int out[3]) {                                                   /* [ref :958-977] */
     if (left != above) {
@@ -296,45 +378,71 @@ static HD void hv_mpm(int left, int above, int out[3]) {                        
         out[0] = left; out[1] = ((left + 29) & 31) + 2; out[2] = ((left - 1) & 31) + 2;
     } else { out[0] = 0; out[1] = 1; out[2] = 26; }
 }
-/* prev_intra_luma_pred_flag for every part first, then mpm_idx / rem_intra_luma_pred_mode  [ref :985-1018] */
-static HD void hv_put_modes(const HvLds &S, HvCod &c, u8 *cx, int parts, const int *mode, const int *left, const int *above) {
+
+struct HvModes { int mode[4], left[4], above[4]; };
+
+/* CU header slot: split_cu_flag=0, part_mode, luma modes (all prev_intra_luma_pred_flags first, then mpm_idx /
+   rem_intra_luma_pred_mode), chroma mode, split_transform_flag, cbf_cb, cbf_cr   [ref :943-1033, 1282-1287] */
+static HD int hv_tokenize_cu(u16 *slot, int n, int lg, int kind, int split_inc, const HvModes &pm) {
+    HvTokW w = { slot, 0 };
+    if (n >= 16) hv_tok_ctx(w, CX_SPLIT_CU + split_inc, 0);
+    if (n == 8) hv_tok_ctx(w, CX_PART, kind != 2);
+    const int parts = kind == 2 ? 4 : 1;
     int hit[4], rem[4];
-    for (int i = 0; i < parts; i++) {
-        int p[3];
-        hv_mpm(left[i], above[i], p);
-        int h = -1;
-        for (int j = 0; j < 3; j++) if (p[j] == mode[i]) h = j;
-        hit[i] = h;
-        /* descending sort of the three candidates, then skip them */
-        int a = p[0], b = p[1], d = p[2], t;
-        if (a < b) { t = a; a = b; b = t; }
-        if (b < d) { t = b; b = d; d = t; }
-        if (a < b) { t = a; a = b; b = t; }
-        int r = mode[i];
-        if (r > a) r--;
-        if (r > b) r--;
-        if (r > d) r--;
-        rem[i] = r;
-        hv_bin(S, c, HV_CX(CX_YPM), h >= 0);
+    for (int i = 0; i < 4; i++) {
+        if (i < parts) {
+            int p[3];
+            hv_mpm(pm.left[i], pm.above[i], p);
+            int h = -1;
+            for (int j = 0; j < 3; j++) if (p[j] == pm.mode[i]) h = j;
+            int a = p[0], b = p[1], d = p[2], t;                   /* descending sort, then skip the candidates */
+            if (a < b) { t = a; a = b; b = t; }
+            if (b < d) { t = b; b = d; d = t; }
+            if (a < b) { t = a; a = b; b = t; }
+            int r = pm.mode[i];
+            if (r > a) r--;
+            if (r > b) r--;
+            if (r > d) r--;
+            hit[i] = h; rem[i] = r;
+            hv_tok_ctx(w, CX_YPM, h >= 0);
+        }
     }
-    for (int i = 0; i < parts; i++) {
-        if (hit[i] >= 0) {
-            hv_bypass(c, hit[i] > 0, 1);
-            if (hit[i] > 0) hv_bypass(c, hit[i] - 1, 1);
-        } else hv_bypass(c, rem[i], 5);
+    for (int i = 0; i < 4; i++) {
+        if (i < parts) {
+            if (hit[i] >= 0) { hv_tok_byp(w, hit[i] > 0, 1); if (hit[i] > 0) hv_tok_byp(w, hit[i] - 1, 1); }
+            else hv_tok_byp(w, rem[i], 5);
+        }
     }
+    hv_tok_ctx(w, CX_UVPM, 0);
+    if (kind != 2) hv_tok_ctx(w, CX_SPLIT_TU + (5 - lg), kind == 1);
+    hv_tok_ctx(w, CX_UVCBF, 0);
+    hv_tok_ctx(w, CX_UVCBF, 0);
+    slot[0] = (u16)w.n;
+    return w.n;
 }
 
-static HD void hv_put_last(const HvLds &S, HvCod &c, u8 *cx, int n, int lg, int swap, int y, int x) {     /* [ref :1046-1087] */
-    const int cls = lg - 2, sh = (n == 4) ? 0 : 1;
-    int ty = swap ? x : y, tx = swap ? y : x;
-    const int gy = hv_lastgrp[ty], gx = hv_lastgrp[tx], gmax = hv_lastgrp[n - 1];
-    for (int i = 0; i < gx; i++) hv_bin(S, c, HV_CX(CX_LASTX + 5 * cls + (i >> sh)), 1);
-    if (gx < gmax)               hv_bin(S, c, HV_CX(CX_LASTX + 5 * cls + (gx >> sh)), 0);
-    for (int i = 0; i < gy; i++) hv_bin(S, c, HV_CX(CX_LASTY + 5 * cls + (i >> sh)), 1);
-    if (gy < gmax)               hv_bin(S, c, HV_CX(CX_LASTY + 5 * cls + (gy >> sh)), 0);
-    if (gx > 3) { tx -= hv_lastmin[gx]; for (int i = ((gx - 2) >> 1) - 1; i >= 0; i--) hv_bypass(c, (tx >> i) & 1, 1); }
-    if (gy > 3) { ty -= hv_lastmin[gy]; for (int i = ((gy - 2) >> 1) - 1; i >= 0; i--) hv_bypass(c, (ty >> i) & 1, 1); }
+/* TU header slot: cbf_luma (unless the caller is the NxN sub-search, which codes bare residuals) and the position of
+   the last significant coefficient   [ref :1038-1087, 1192] */
+static HD int hv_tokenize_tu(const HvLds &S, u16 *slot, int n, int lg, int kind_scan, int with_cbf, int cbf_ctx, int cbf, int last) {
+    HvTokW w = { slot, 0 };
+    if (with_cbf) hv_tok_ctx(w, cbf_ctx, cbf);
+    if (cbf || !with_cbf) {
+        int gy, gx, iy, ix;
+        hv_scan_cg(S, lg, kind_scan, last >> 4, gy, gx);
+        hv_scan_in(S, kind_scan, last & 15, iy, ix);
+        const int y = gy * 4 + iy, x = gx * 4 + ix;
+        const int cls = lg - 2, sh = (n == 4) ? 0 : 1;
+        int ty = kind_scan == 2 ? x : y, tx = kind_scan == 2 ? y : x;
+        const int ggy = hv_lastgrp[ty], ggx = hv_lastgrp[tx], gmax = hv_lastgrp[n - 1];
+        for (int i = 0; i < ggx; i++) hv_tok_ctx(w, CX_LASTX + 5 * cls + (i >> sh), 1);
+        if (ggx < gmax)               hv_tok_ctx(w, CX_LASTX + 5 * cls + (ggx >> sh), 0);
+        for (int i = 0; i < ggy; i++) hv_tok_ctx(w, CX_LASTY + 5 * cls + (i >> sh), 1);
+        if (ggy < gmax)               hv_tok_ctx(w, CX_LASTY + 5 * cls + (ggy >> sh), 0);
+        if (ggx > 3) { tx -= hv_lastmin[ggx]; for (int i = ((ggx - 2) >> 1) - 1; i >= 0; i--) hv_tok_byp(w, (tx >> i) & 1, 1); }
+        if (ggy > 3) { ty -= hv_lastmin[ggy]; for (int i = ((ggy - 2) >> 1) - 1; i >= 0; i--) hv_tok_byp(w, (ty >> i) & 1, 1); }
+    }
+    slot[0] = (u16)(w.n | HV_HDR_RESET);
+    return w.n | HV_HDR_RESET;
 }
 
 static HD int hv_sigctx(int n, int diag, int y, int x, int nb) {                                           /* [ref :1092-1122] */
@@ -351,115 +459,166 @@ static HD int hv_sigctx(int n, int diag, int y, int x, int nb) {                
     return base + 2;
 }
 
-static HD void hv_put_remainder(HvCod &c, int v, int k) {                                                  /* [ref :1154-1169] */
+static HD void hv_tok_remainder(HvTokW &w, int v, int k) {                                                 /* [ref :1154-1169] */
     if (v < (3 << k)) {
         const int pre = v >> k;
-        hv_bypass(c, (1 << (pre + 1)) - 2, pre + 1);
-        hv_bypass(c, v & ((1 << k) - 1), k);
+        hv_tok_byp(w, (1 << (pre + 1)) - 2, pre + 1);
+        hv_tok_byp(w, v & ((1 << k) - 1), k);
     } else {
         int len = k;
         v -= 3 << k;
-        for (; len < 20 && v >= (1 << len); len++) v -= 1 << len;      /* levels are 16-bit: len <= 15; bounded against garbage */
+        for (; len < 20 && v >= (1 << len); len++) v -= 1 << len;      /* levels are 16-bit: len <= 15 */
         const int t = 4 + len - k;
-        hv_bypass(c, (1 << t) - 2, t);
-        hv_bypass(c, v, len);
+        hv_tok_byp(w, (1 << t) - 2, t);
+        hv_tok_byp(w, v, len);
     }
 }
 
-/* residual_coding() of one luma TU whose levels are stored in SCAN ORDER at lev[0..n*n)   [ref :1173-1269]
-   last / cgsig come from the TU job that produced the levels; slot selects the lane-private staging rows */
-static HDN HvCod hv_put_residual(HvCod c, int slot, int n, int lg, int mode,
-                                 const short *lev, int last, u64 cgsig) {
-    HvLds &S = HV_S;
-    u8 *cx = &S.tctx[0][slot];      /* n, lg, mode are PER-LANE here: lanes of one wave encode different candidates */
-    const int kind = hv_scan_kind(n, mode), ncg = n >> 2;
-    short *buf = S.cgbuf[slot], *absv = S.absbuf[slot];
-    int gy = 0, gx = 0, iy, ix;
-    hv_scan_cg(S, lg, kind, last >> 4, gy, gx);
-    hv_scan_in(S, kind, last & 15, iy, ix);
-    hv_put_last(S, c, cx, n, lg, kind == 2, gy * 4 + iy, gx * 4 + ix);
-
-    int nz = 0, signs = 0, nb = 0, c1 = 1, cgs = 0, first_cg = 0;
-    for (int i = last; i >= 0; i--) {
-        const int ii = i & 15;
-        const int at_last = (i == last), cg_first = (ii == 0), cg_enter = (ii == 15) || at_last;
-        if (cg_enter) {
-            const int cg = i >> 4;
-            hv_scan_cg(S, lg, kind, cg, gy, gx);
-            first_cg = (cg == 0);
-            cgs = (int)((cgsig >> (gy * 8 + gx)) & 1);
-            const int right = (gx < ncg - 1) ? (int)((cgsig >> (gy * 8 + gx + 1)) & 1) : 0;
-            const int below = (gy < ncg - 1) ? (int)((cgsig >> (gy * 8 + 8 + gx)) & 1) : 0;
-            nb = (below << 1) | right; nz = 0; signs = 0;
-            if (!first_cg && !at_last) hv_bin(S, c, HV_CX(CX_SIGCG + (nb != 0)), cgs);
-            if (cgs) {
-                const short *src = lev + (cg << 4);
-                for (int k = 0; k < 16; k++) buf[k] = src[k];
-            } else if (!first_cg) {
-                i = cg << 4;          /* an all-zero group that is not the first one carries no further bins */
-                continue;
-            }
-        }
-        const int v = cgs ? buf[ii] : 0;
-        if (!at_last && (first_cg || (cgs && (!cg_first || nz > 0)))) {
-            hv_scan_in(S, kind, ii, iy, ix);
-            hv_bin(S, c, HV_CX(CX_SIG + hv_sigctx(n, kind == 0, gy * 4 + iy, gx * 4 + ix, nb)), v != 0);
-        }
-        if (v) { absv[nz++] = (short)hv_abs(v); signs = (signs << 1) | (v < 0); }
-        if (cg_first && nz > 0) {
-            const int set = (first_cg ? 0 : 2) + (c1 == 0);
-            int esc = nz > 8, g2 = -1;
-            c1 = 1;
-            for (int j = 0; j < 8 && j < nz; j++) {
-                const int a = absv[j];
-                hv_bin(S, c, HV_CX(CX_ONE + 4 * set + c1), a > 1);
-                if (a > 1) { c1 = 0; if (g2 < 0) g2 = a > 2; else esc = 1; }
-                else if (c1 > 0 && c1 < 3) c1++;
-            }
-            if (c1 == 0 && g2 >= 0) { hv_bin(S, c, HV_CX(CX_ABS + set), g2); esc |= g2; }
-            hv_bypass(c, signs, nz);
-            if (esc) {
-                int base = 3, rice = 0;
-                for (int j = 0; j < nz; j++) {
-                    const int a = absv[j], rem = a - (j < 8 ? base : 1);
-                    if (rem >= 0) {
-                        hv_put_remainder(c, rem, rice);
-                        if (a > (3 << rice)) rice = hv_min(rice + 1, 4);
+/* one 4x4 coefficient group of a transform block whose levels lie in SCAN ORDER at lev16[0..15]   [ref :1194-1268]
+   cg = the group's index in scan order; last / cgsig describe the whole block (from the TU job).
+   Every loop below has a fixed trip count with predication, so that threads binarising different groups stay converged. */
+static HD int hv_tokenize_cg(const HvLds &S, u16 *slot, const short *lev16, int n, int lg, int kind, int cg, int last, u64 cgsig) {
+    HvTokW w = { slot, 0 };
+    const int cg_last = last >> 4;
+    int hdr = 0;
+    if (cg <= cg_last) {
+        int gy, gx;
+        hv_scan_cg(S, lg, kind, cg, gy, gx);
+        const int ncg = n >> 2, first_cg = (cg == 0), at_last_cg = (cg == cg_last);
+        const int cgs = (int)((cgsig >> (gy * 8 + gx)) & 1);
+        const int right = (gx < ncg - 1) ? (int)((cgsig >> (gy * 8 + gx + 1)) & 1) : 0;
+        const int below = (gy < ncg - 1) ? (int)((cgsig >> (gy * 8 + 8 + gx)) & 1) : 0;
+        const int nb = (below << 1) | right;
+        if (!first_cg && !at_last_cg) hv_tok_ctx(w, CX_SIGCG + (nb != 0), cgs);
+        if (cgs || first_cg) {
+            const int start = at_last_cg ? (last & 15) : 15;
+            int v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = cgs ? (int)lev16[k] : 0;
+            /* significance flags, highest scan position first */
+            int nz = 0, signs = 0;
+#pragma unroll
+            for (int ii = 15; ii >= 0; ii--) {
+                if (ii <= start) {
+                    const int at_last = at_last_cg && ii == start;
+                    if (!at_last && (first_cg || (cgs && (ii != 0 || nz > 0)))) {
+                        int iy, ix;
+                        hv_scan_in(S, kind, ii, iy, ix);
+                        hv_tok_ctx(w, CX_SIG + hv_sigctx(n, kind == 0, gy * 4 + iy, gx * 4 + ix, nb), v[ii] != 0);
                     }
-                    if (a >= 2) base = 2;
+                    if (v[ii]) { nz++; signs = (signs << 1) | (v[ii] < 0); }
                 }
             }
+            if (nz > 0) {
+                /* greater1 flags of the first eight, one greater2 flag; the context set remembers the previous group */
+                const int set4 = (first_cg ? 0 : 8), set1 = (first_cg ? 0 : 2);
+                int esc = nz > 8, g2 = -1, c1 = 1, j = 0;
+#pragma unroll
+                for (int ii = 15; ii >= 0; ii--) {
+                    if (ii <= start && v[ii] && j < 8) {
+                        const int a = hv_abs(v[ii]);
+                        w.p[HV_SLOT_TOK0 + w.n] = (u16)((CX_ONE + set4 + c1) | (a > 1 ? 0x80 : 0) | HV_TOK_G4); w.n++;
+                        if (a > 1) { c1 = 0; if (g2 < 0) g2 = a > 2; else esc = 1; }
+                        else if (c1 > 0 && c1 < 3) c1++;
+                        j++;
+                    }
+                }
+                if (c1 == 0 && g2 >= 0) { w.p[HV_SLOT_TOK0 + w.n] = (u16)((CX_ABS + set1) | (g2 ? 0x80 : 0) | HV_TOK_G1); w.n++; esc |= g2; }
+                hv_tok_byp(w, signs, nz);
+                if (esc) {
+                    int base = 3, rice = 0;
+                    j = 0;
+#pragma unroll
+                    for (int ii = 15; ii >= 0; ii--) {
+                        if (ii <= start && v[ii]) {
+                            const int a = hv_abs(v[ii]), rem = a - (j < 8 ? base : 1);
+                            if (rem >= 0) {
+                                hv_tok_remainder(w, rem, rice);
+                                if (a > (3 << rice)) rice = hv_min(rice + 1, 4);
+                            }
+                            if (a >= 2) base = 2;
+                            j++;
+                        }
+                    }
+                }
+                hdr = HV_HDR_NZ | (c1 == 0 ? HV_HDR_G1 : 0);
+            }
         }
     }
-    return c;
+    slot[0] = (u16)(w.n | hdr);
+    return w.n | hdr;
 }
 
-/* coding_unit() after split_cu_flag: kind 0 = one TU, 1 = four TUs, 2 = NxN   [ref :1272-1340] */
-struct HvModes { int mode[4], left[4], above[4]; };
-static HDN HvCod hv_put_cu(HvCod c, int slot, int n, int lg, int kind, HvModes pm,
-                           const short *lev0, int lev_step) {
-    HvLds &S = HV_S;
-    u8 *cx = &S.tctx[0][slot];
-    const HvTuInfo *info = S.tinfo[slot];
-    const int *mode = pm.mode, *left = pm.left, *above = pm.above;
-    n = hv_uni(n); lg = hv_uni(lg);   /* the CU size is wave-uniform; kind is per-lane */
-    if (n == 8) hv_bin(S, c, HV_CX(CX_PART), kind != 2);
-    hv_put_modes(S, c, cx, kind == 2 ? 4 : 1, mode, left, above);
-    hv_bin(S, c, HV_CX(CX_UVPM), 0);
-    if (kind != 2) hv_bin(S, c, HV_CX(CX_SPLIT_TU + (5 - lg)), kind == 1);
-    hv_bin(S, c, HV_CX(CX_UVCBF), 0);
-    hv_bin(S, c, HV_CX(CX_UVCBF), 0);
-    if (kind == 0) {
-        hv_bin(S, c, HV_CX(CX_YCBF + 1), info[0].cbf);
-        if (info[0].cbf) c = hv_put_residual(c, slot, n, lg, mode[0], lev0, info[0].last, info[0].cgsig);
-    } else {
-        for (int s = 0; s < 4; s++) {
-            hv_bin(S, c, HV_CX(CX_YCBF + 0), info[s].cbf);
-            if (info[s].cbf)
-                c = hv_put_residual(c, slot, n >> 1, lg - 1, mode[kind == 2 ? s : 0], lev0 + s * lev_step, info[s].last, info[s].cgsig);
-        }
+/* Final token format in a LINKED stream (one contiguous stream per candidate, see hv_link_*):
+     context bin : bit15=0, bit14 = bin value, bits0-12 = byte offset of the context inside the candidate's column
+                   (index * HV_TL), with the greater1/greater2 set memory already resolved
+     bypass chunk: bit15=1, bits8-11 length, bits0-7 bins (length 0 = no-op padding)                              */
+#define HV_CX(i) (cx + (i) * HV_TL)
+#define HV_TOK_NOP HV_TOK_BYP
+typedef unsigned HvChunk __attribute__((vector_size(16)));   /* eight 16-bit tokens, loaded as one dwordx4 */
+static HD int hv_chunk_get(const HvChunk &c, int i) {
+    const unsigned lo = (i & 4) ? c[2] : c[0], hi = (i & 4) ? c[3] : c[1];
+    const unsigned d = (i & 2) ? hi : lo;
+    return (int)((d >> ((i & 1) << 4)) & 0xffffu);
+}
+static HD int hv_link_token(int tok, int g1) {
+    if (tok & HV_TOK_BYP) return tok;
+    const int idx = (tok & 0x7f) + (g1 ? (((tok >> 13) & 1) << 2) + ((tok >> 14) & 1) : 0);
+    return (idx * HV_TL) | (((tok >> 7) & 1) << 14);
+}
+
+/* The arithmetic engine of one candidate over its linked stream of ntok tokens (chunk pointer, 16-byte aligned).
+   cx = &S.tctx[0][trial].  All lanes of a wavefront run this loop in lockstep; one iteration = one token through the
+   same straight-line code for context-coded bins and bypass chunks; the next 8-token chunk is requested 8 tokens ahead.
+   Pruning (exact): a candidate's cost w1*sse + w2*bits only grows while it is being encoded, so once its partial cost
+   exceeds the cost of a candidate that has COMPLETED (or of the split alternative, known beforehand) it cannot be the
+   arg-min, which is the LAST candidate of MINIMAL cost (ref :1440 adopts on >=).  Returns 1 when abandoned.
+   [ref CABACputBin / CABACputBins :899-933] */
+template <typename ChunkPtr>
+static HD int hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int ntok, int q = 0, int sse = 0, int bits0 = 0, const int *best = nullptr) {
+    HvChunk cur = sp[0], nxt = sp[1];
+    for (int i = 0; i < ntok; i++) {
+        if ((i & 7) == 0 && i) { cur = nxt; nxt = sp[(i >> 3) + 1]; }
+        const int tok = hv_chunk_get(cur, i & 7);
+        const int isb = (tok >> 15) & 1;
+        const int nb = (tok >> 8) & 15, bv = tok & 0xff;
+        u8 *cp = cx + (isb ? (HEVCE_NCTXP - 1) * HV_TL : (tok & 0x1fff));        /* bypass: pad context, written back unchanged */
+#ifdef HEVCE_ABL_NOLDS
+        const int cv = (tok * 37) & 127, st = cv >> 1, mps = cv & 1;
+        const unsigned lw = 0x30405060u + st;
+        const int lnx = st >> 1;
+#else
+        const int cv = *cp, st = cv >> 1, mps = cv & 1;
+        const unsigned lw = S.lps4[st];
+        const int lnx = S.lpsnext[st];
+#endif
+        const int lps = (int)((lw >> (((c.range >> 6) & 3) << 3)) & 0xff);
+        const int islps = (((tok >> 14) & 1) ^ mps);
+        const int rm = c.range - lps;
+        const int shl = (lps < 8) ? 6 : hv_clz((unsigned)(lps >> 3)) - 26;
+        const int shm = (rm < 256) ? 1 : 0;
+        const int cvl = (st == 0) ? (mps ^ 1) : ((lnx << 1) | mps);
+        const int cvm = (st < 62) ? cv + 2 : cv;
+        const unsigned low_c = islps ? ((c.low + (unsigned)rm) << shl) : (c.low << shm);
+        const int range_c = islps ? (lps << shl) : (rm << shm);
+        const int sh_c = islps ? shl : shm;
+        const unsigned low_b = (c.low << nb) + (unsigned)c.range * (unsigned)bv;
+        c.low = isb ? low_b : low_c;
+        c.range = isb ? c.range : range_c;
+        c.nbits -= isb ? nb : sh_c;
+#ifndef HEVCE_ABL_NOLDS
+        *cp = (u8)(isb ? cv : (islps ? cvl : cvm));
+#else
+        c.zeros += (isb ? cv : (islps ? cvl : cvm)) & 1;
+#endif
+#ifndef HEVCE_ABL_NOCARRY
+        hv_cod_carry_fast(c);
+#else
+        if (c.nbits < 12) { c.nbits += 8; c.low &= 0xffffffffu >> c.nbits; c.nout++; }
+#endif
+        if (best && (i & 15) == 15 && hv_rdcost(q, sse, hv_cod_bits(c) - bits0) > hv_peek(best)) return 1;
     }
-    return c;
+    return 0;
 }
 
 /* --------------------------------------------------------------------------------------------- */
@@ -788,6 +947,7 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
     q = hv_uni(q); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x);
     const int slot = lane >> 2, j = lane & 3;
     int total = 0;
+    HV_PROF2_T0();
     for (int s = 0; s < 4; s++) {
         int l, lb, a, ar;
         hv_sub_avail(s, cu.L, cu.LB, cu.A, cu.AR, l, lb, a, ar);
@@ -802,6 +962,7 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
         }
         WAVE_SYNC();
         HV_TRACE(S, 5, s * 100 + 50);
+        HV_PROF2(S, 0);
         /* rate of every candidate: lane = mode  [ref :1505-1519]; residual_coding is written even for an all-zero block */
         int cost = HV_I32MAX, idx = -1;
         if (lane < HEVCE_NMODES) {
@@ -810,14 +971,21 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
             for (int k = 0; k < 9; k++) *HV_CX(CX_SIG + k) = S.ctx_fresh[CX_SIG + k];
             for (int k = 0; k < 4; k++) *HV_CX(CX_ONE + k) = S.ctx_fresh[CX_ONE + k];
             *HV_CX(CX_ABS) = S.ctx_fresh[CX_ABS];
+            *HV_CX(HEVCE_NCTXP - 1) = 0;                          /* pad context used by bypass / no-op tokens */
             HvCod c;
             hv_cod_fresh(c);
-            HV_TRACE_LANE(S, lane, 1000000 + S.nxn_last[lane] * 1000 + S.nxn_sig[lane]);
-            c = hv_put_residual(c, lane, 4, 2, lane, S.nxn_lev[lane], S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0));
-            HV_TRACE_LANE(S, lane, 2000000 + hv_cod_bits(c));
+            u16 *tk = S.nxn_tok[lane];
+            const int ks = hv_scan_kind(4, lane);
+            /* the two slots are laid out so that their tokens are contiguous from tk[8]; one group: no set memory */
+            const int na = hv_tokenize_tu(S, tk, 4, 2, ks, 0, 0, 1, S.nxn_last[lane]) & 0xff;
+            const int nb = hv_tokenize_cg(S, tk + na, S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0)) & 0xff;
+            for (int k = 0; k < na + nb; k++) tk[HV_SLOT_TOK0 + k] = (u16)hv_link_token(tk[HV_SLOT_TOK0 + k], 0);
+            HV_PROF2(S, 1);
+            hv_engine(S, c, cx, (const HvChunk *)(tk + HV_SLOT_TOK0), na + nb);
             cost = hv_rdcost(q, S.nxn_sse[lane], hv_cod_bits(c));
             idx = lane;
         }
+        HV_PROF2(S, 2);
         HV_TRACE(S, 5, s * 100 + 60);
         for (int sft = 1; sft < 64; sft <<= 1) {             /* minimum cost, the LATER mode wins ties  [ref :1521] */
             const int oc = hv_shfl_xor(cost, sft), oi = hv_shfl_xor(idx, sft);
@@ -836,6 +1004,7 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
         }
         total += S.nxn_sse[w];
         WAVE_SYNC();
+        HV_PROF2(S, 3);
     }
     if (lane == 0) S.tsse[70] = total;
 }
@@ -880,6 +1049,7 @@ static HD void hv_eval_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, Hev
     HV_TRACE(S, 2, 100);
     for (int k = tid; k < 8 * 8; k += HV_NTHREADS) (&S.nxn_crec[0][0])[k] = 0;
     BLOCK_SYNC();
+    HV_PROF_T0();
 
     /* ---------------- TU jobs: static round-robin over the wavefronts, longest jobs first ----------------
        (job ids are ordered by cost; rounds alternate direction so that the wave with the longest job gets the
@@ -912,42 +1082,121 @@ static HD void hv_eval_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, Hev
     }
     HV_TRACE(S, 2, 200);
     BLOCK_SYNC();                                               /* the NxN job borrows trial context columns */
+    HV_PROF(S, cu.lvl, 0);
+    if (tid == 0) S.best_cost = (n > 8) ? hv_rdcost(q, S.split_sse, hv_regs_bits(S.com) - hv_regs_bits(S.ent[cu.lvl])) : HV_I32MAX;   /* [ref :1410] */
+    if (tid < HV_TL) S.tdead[tid] = 0;
     /* trial contexts start from the CU's entry snapshot  [ref :1423-1424] */
     for (int k = tid; k < HEVCE_NCTXP * HV_TL; k += HV_NTHREADS) S.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[cu.lvl][k / HV_TL];
     BLOCK_SYNC();
 
+    HV_PROF(S, cu.lvl, 1);
     HV_TRACE(S, 2, 300);
-    /* ---------------- trial encodes: lane = candidate  [ref :1434-1438, 1470-1474, 1540-1544] ---------------- */
+    /* ---------------- binarisation: one work item per slot of every candidate (data-parallel) ----------------
+       [ref :1434-1435, 1470-1471, 1540-1541 call the syntax writers per candidate; here only their bins are formed] */
+    u16 *gtok = (u16 *)(im.scratch + HV_TL * 1024 * 3);
+    {
+        /* slot f of candidate t: f = 0 CU header; then per transform block (1 for candidates 0..34, 4 otherwise) a header
+           slot followed by its 4x4 groups from the highest scan index down -- the order the engine consumes them.
+           Work items are dense and grouped by kind (all group slots, then block headers, then CU headers) so that the
+           threads of a wavefront execute the same binarisation path. */
+        const int h = n >> 1, ncg_cu = (n >> 2) * (n >> 2);
+        for (int item = tid; item < ntrials * ncg_cu; item += HV_NTHREADS) {          /* 4x4 group slots */
+            const int t = item / ncg_cu, gi = item % ncg_cu;
+            const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
+            const int tn = kind == 0 ? n : h, tlg = kind == 0 ? cu.lg : cu.lg - 1, ncgt = (tn >> 2) * (tn >> 2);
+            const int tu = gi / ncgt, r = gi % ncgt, cg = ncgt - 1 - r;
+            u16 *slot = gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt) + 1 + r) * HV_SLOT;
+            if (hv_rdcost(q, S.tsse[t], 0) > S.best_cost) continue;                 /* cannot win: never encoded */
+            u16 &sh = S.shdr[t][1 + tu * (1 + ncgt) + 1 + r];
+            if (!S.tinfo[t][tu].cbf) { sh = 0; continue; }
+            const int md = kind == 0 ? t : kind == 1 ? t - 35 : S.nxn_modes[tu];
+            const short *lev = (kind == 2) ? &S.nxn_bestlev[tu][0] : glev + t * 1024 + tu * tn * tn;
+            sh = (u16)hv_tokenize_cg(S, slot, lev + cg * 16, tn, tlg, hv_scan_kind(tn, md), cg, S.tinfo[t][tu].last, S.tinfo[t][tu].cgsig);
+        }
+        for (int item = tid; item < ntrials * 4; item += HV_NTHREADS) {               /* transform-block header slots */
+            const int t = item >> 2, tu = item & 3;
+            const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
+            if (kind == 0 && tu > 0) continue;
+            if (hv_rdcost(q, S.tsse[t], 0) > S.best_cost) continue;
+            const int tn = kind == 0 ? n : h, tlg = kind == 0 ? cu.lg : cu.lg - 1, ncgt = (tn >> 2) * (tn >> 2);
+            const int md = kind == 0 ? t : kind == 1 ? t - 35 : S.nxn_modes[tu];
+            u16 *slot = gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt)) * HV_SLOT;
+            S.shdr[t][1 + tu * (1 + ncgt)] = (u16)hv_tokenize_tu(S, slot, tn, tlg, hv_scan_kind(tn, md), 1, kind == 0 ? CX_YCBF + 1 : CX_YCBF, S.tinfo[t][tu].cbf, S.tinfo[t][tu].last);
+        }
+        for (int t = tid; t < ntrials; t += HV_NTHREADS) {                            /* CU header slots */
+            const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
+            if (hv_rdcost(q, S.tsse[t], 0) > S.best_cost) continue;
+            HvModes pm;
+            for (int s4 = 0; s4 < 4; s4++) { pm.mode[s4] = 0; pm.left[s4] = 0; pm.above[s4] = 0; }
+            pm.left[0] = ml; pm.above[0] = ma;
+            if (kind == 0) pm.mode[0] = t;
+            else if (kind == 1) pm.mode[0] = t - 35;
+            else {
+                for (int s4 = 0; s4 < 4; s4++) pm.mode[s4] = S.nxn_modes[s4];
+                pm.left[1] = pm.mode[0];  pm.above[1] = S.map_pm[my - 1][mx + 1];                 /* [ref :1531-1538] */
+                pm.left[2] = S.map_pm[my + 1][mx - 1];  pm.above[2] = pm.mode[0];
+                pm.left[3] = pm.mode[2];  pm.above[3] = pm.mode[1];
+            }
+            S.shdr[t][0] = (u16)hv_tokenize_cu(gtok + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT, n, cu.lg, kind, split_inc, pm);
+        }
+    }
+    BLOCK_SYNC();
+    /* ---------------- link: slot offsets and greater1-set memory per candidate, then one contiguous stream each -------- */
+    u16 *gstream = gtok + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT;
+    for (int t = tid; t < ntrials; t += HV_NTHREADS) {
+        int off = 0;
+        if (!(hv_rdcost(q, S.tsse[t], 0) > S.best_cost)) {
+            const int tn = t < 35 ? n : (n >> 1);
+            const int nslots = 1 + (t < 35 ? 1 : 4) * (1 + (tn >> 2) * (tn >> 2));
+            int g1 = 0;
+            for (int f = 0; f < nslots; f++) {
+                const int hdr = S.shdr[t][f];
+                if (hdr & HV_HDR_RESET) g1 = 0;
+                S.shdr[t][f] = (u16)(off | (g1 << 15));
+                if (hdr & HV_HDR_NZ) g1 = (hdr & HV_HDR_G1) ? 1 : 0;
+                off += hdr & 0xff;
+            }
+            S.shdr[t][nslots] = (u16)off;
+        }
+        S.tlen[t] = off;
+    }
+    BLOCK_SYNC();
+    for (int item = tid; item < ntrials * HV_SLOTS_TRIAL; item += HV_NTHREADS) {
+        const int t = item / HV_SLOTS_TRIAL, f = item % HV_SLOTS_TRIAL;
+        const int tn = t < 35 ? n : (n >> 1);
+        const int nslots = 1 + (t < 35 ? 1 : 4) * (1 + (tn >> 2) * (tn >> 2));
+        if (f >= nslots || S.tlen[t] == 0) continue;
+        const int o0 = S.shdr[t][f], off = o0 & 0x7fff, g1 = o0 >> 15, cnt = (S.shdr[t][f + 1] & 0x7fff) - off;
+        const HV_GLOBAL HvChunk *src = (const HV_GLOBAL HvChunk *)(gtok + (size_t)item * HV_SLOT + HV_SLOT_TOK0);
+        HV_GLOBAL u16 *dst = (HV_GLOBAL u16 *)(gstream + (size_t)t * HEVCE_STREAM_WORDS + off);
+        for (int k0 = 0; k0 < cnt; k0 += 8) {
+            const HvChunk ch = src[k0 >> 3];
+            for (int j = 0; j < 8; j++) if (k0 + j < cnt) dst[k0 + j] = (u16)hv_link_token(hv_chunk_get(ch, j), g1);
+        }
+    }
+    BLOCK_SYNC();
+    HV_PROF(S, cu.lvl, 5);
+
+    /* ---------------- arithmetic engine: lane = candidate, all lanes in lockstep over their token streams ------------ */
     {
         const int t = lane * HV_NWAVES + wave;                  /* spread the candidates over all wavefronts */
         if (lane < 9 && t < ntrials) {
             HvCod c;
             hv_cod_load(c, S.ent[cu.lvl]);
             const int bits0 = hv_cod_bits(c);
-            u8 *cx = &S.tctx[0][t];
-            if (n >= 16) hv_bin(S, c, HV_CX(CX_SPLIT_CU + split_inc), 0);
-            HvModes pm;
-            for (int s4 = 0; s4 < 4; s4++) { pm.mode[s4] = 0; pm.left[s4] = 0; pm.above[s4] = 0; }
-            pm.left[0] = ml; pm.above[0] = ma;
-            if (t < 35) {
-                pm.mode[0] = t;
-                c = hv_put_cu(c, t, n, cu.lg, 0, pm, glev + t * 1024, 0);
-            } else if (t < 70) {
-                pm.mode[0] = t - 35;
-                c = hv_put_cu(c, t, n, cu.lg, 1, pm, glev + t * 1024, (n >> 1) * (n >> 1));
-            } else {
-                for (int s4 = 0; s4 < 4; s4++) pm.mode[s4] = S.nxn_modes[s4];
-                pm.left[1] = pm.mode[0];  pm.above[1] = S.map_pm[my - 1][mx + 1];                 /* [ref :1531-1538] */
-                pm.left[2] = S.map_pm[my + 1][mx - 1];  pm.above[2] = pm.mode[0];
-                pm.left[3] = pm.mode[2];  pm.above[3] = pm.mode[1];
-                c = hv_put_cu(c, t, 8, 3, 2, pm, &S.nxn_bestlev[0][0], 16);
-            }
-            S.tcost[t] = hv_rdcost(q, S.tsse[t], hv_cod_bits(c) - bits0);
+            int dead = hv_rdcost(q, S.tsse[t], 0) > S.best_cost;          /* same test the binarisation used (best_cost only changes below) */
+            if (!dead) dead = hv_engine(S, c, &S.tctx[0][t], (const HV_GLOBAL HvChunk *)(gstream + (size_t)t * HEVCE_STREAM_WORDS), S.tlen[t],
+                                        q, S.tsse[t], bits0, &S.best_cost);
+            const int cost = dead ? HV_I32MAX : hv_rdcost(q, S.tsse[t], hv_cod_bits(c) - bits0);
+            S.tcost[t] = cost;
+            S.tdead[t] = (u8)dead;
+            if (!dead) hv_atomic_min(&S.best_cost, cost);
             hv_cod_store(S.tregs[t], c);
         }
     }
     BLOCK_SYNC();
 
+    HV_PROF(S, cu.lvl, 2);
     if (dump && tid < HV_TL) {
         int32_t *d = dump + 16 * tid;
         const bool v = tid < ntrials;
@@ -969,11 +1218,12 @@ static HD void hv_eval_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, Hev
     if (tid == 0) {
         int best = HV_I32MAX, w = -1;
         if (n > 8) best = hv_rdcost(q, S.split_sse, hv_regs_bits(S.com) - hv_regs_bits(S.ent[cu.lvl]));
-        for (int t = 0; t < ntrials; t++) if (best >= S.tcost[t]) { best = S.tcost[t]; w = t; }
+        for (int t = 0; t < ntrials; t++) if (!S.tdead[t] && best >= S.tcost[t]) { best = S.tcost[t]; w = t; }
         S.winner = w;
     }
     BLOCK_SYNC();
     const int w = S.winner;
+    HV_PROF(S, cu.lvl, 3);
     HV_TRACE(S, 2, 500);
     if (w < 0) return;                                          /* the four sub-CUs stay */
 
@@ -1005,6 +1255,7 @@ static HD void hv_eval_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, Hev
         rec->info[(cu.y >> 2) + i][(cu.x >> 2) + jx] = (u8)(cu.lvl | (kindw == 2 ? HEVCE_INFO_NXN : 0) | (kindw == 1 ? HEVCE_INFO_TUSPLIT : 0));
     }
     BLOCK_SYNC();
+    HV_PROF(S, cu.lvl, 4);
 }
 
 /* --------------------------------------------------------------------------------------------- */
@@ -1042,6 +1293,8 @@ static HD void hv_snapshot(HvLds &S, int lvl, int tid) {
 static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int tid = hv_tid(), q = im.qpd6, H = im.H, W = im.W;
     if (tid == 0) S.trace = im.trace;
+    if (tid < 24) (&S.prof[0][0])[tid] = 0;
+    if (tid < 8) S.prof2[tid] = 0;
     BLOCK_SYNC();
     HV_TRACE(S, 0, 1);
     hv_init_tables(S, q, tid);
@@ -1128,4 +1381,8 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
             BLOCK_SYNC();
         }
     }
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+    if (im.trace && tid < 24) { ((unsigned long long *)im.trace)[tid] = (&S.prof[0][0])[tid]; }
+    if (im.trace && tid < 8) { ((unsigned long long *)im.trace)[24 + tid] = S.prof2[tid]; }
+#endif
 }

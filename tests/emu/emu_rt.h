@@ -41,6 +41,8 @@ static inline int hv_bcast0(int v) {
     return r;
 }
 static inline int hv_atomic_inc(int *p) { return (*p)++; }
+static inline void hv_atomic_min(int *p, int v) { if (v < *p) *p = v; }
+static inline int hv_peek(const int *p) { return *p; }
 static inline int hv_mul24(int a, int b) {
     if (a < -(1 << 23) || a >= (1 << 23) || b < -(1 << 23) || b >= (1 << 23)) { fprintf(stderr, "emu: mul24 operand out of range %d %d\n", a, b); abort(); }
     return a * b;

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Per-phase cycle profile (HEVCE_PROF build): shares of TU jobs / trial-context init / trial encodes / arg-min / commit."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HEVCE_LIB", os.path.join(ROOT, "hevc-image-encoder-lite_amd", "lib", "libhevce_prof.so"))
+os.environ["HEVCE_TRACE"] = "1"
+import numpy as np
+import hevce_pkg, hevce_workload as wl
+hevce = hevce_pkg.load()
+h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (128, 256)
+img = wl.gen_g2(h, w, 16)
+with hevce.Job([img.shape], 2) as job:
+    job.upload(0, img); job.run()
+    tr = job.trace(0); tm = job.timings()
+prof = tr[:48].view(np.uint64).reshape(3, 8)
+nctu = (hevce.pad32(h) // 32) * (hevce.pad32(w) // 32)
+tot = prof.sum()
+print(f"{w}x{h}: kernel {tm['kernel_ms']:.1f} ms, {tm['kernel_ms']*1e3/nctu:.0f} us/CTU, stamped cycles {tot/1e6:.1f} M ({tot/nctu/1e3:.0f} k/CTU)")
+names = ["TU jobs", "ctx init", "engine", "arg-min", "commit", "binarise"]
+p2 = tr[48:64].view(np.uint64)
+print("  NxN job:", "  ".join(f"{nm} {100.0*p2[i]/tot:5.1f}%" for i, nm in enumerate(("tu jobs", "tokenise", "engine", "select"))))
+for lvl, nm in enumerate(("8x8", "16x16", "32x32")):
+    print(f"  CU {nm:6s}", "  ".join(f"{names[p]} {100.0*prof[lvl,p]/tot:5.1f}%" for p in range(6)))
