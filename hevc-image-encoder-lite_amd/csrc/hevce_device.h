@@ -19,17 +19,17 @@
 #ifdef HEVCE_EMU
 #include "emu_rt.h"
 #define HV_GLOBAL
+#define HV_LDSP
 #define HV_KEEP(x) do { } while (0)
 #else
 #include <hip/hip_runtime.h>
 #define HD  __device__ __forceinline__
 #define HDN __device__ __noinline__
 #define DEVCONST __constant__ const
-/* WAVE_SYNC: lanes of ONE wavefront exchange data through memory.  TU jobs write levels / reconstruction through generic
-   pointers (flat stores into LDS or HBM) and other lanes read them back with ds_/flat loads; flat and DS operations of a
-   wave are not ordered against each other, so the fence must drain both counters (workgroup-scope release/acquire =
-   s_waitcnt vmcnt(0) lgkmcnt(0)), not merely stop compiler reordering. */
-#ifdef HEVCE_WSYNC_WEAK
+/* WAVE_SYNC: lanes of ONE wavefront exchange data through LDS.  Every such access is a ds_* instruction (all hot
+   pointers are typed by address space, never generic/flat), and a wave's ds_* operations execute in order, so the
+   fence only has to stop compiler reordering.  HBM stores of a TU job are consumed after the next workgroup barrier. */
+#ifndef HEVCE_WSYNC_STRONG
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #else
@@ -43,7 +43,8 @@
 #define BLOCK_SYNC() __syncthreads()
 #endif
 #define HV_KEEP(x) asm volatile("" : "+v"(x))          /* pins the first use of a prefetched value to this point */
-#define HV_GLOBAL __attribute__((address_space(1)))    /* pointer known to address HBM: global_load instead of flat_load */
+#define HV_GLOBAL __attribute__((address_space(1)))    /* pointer known to address HBM: global_* instead of flat_* */
+#define HV_LDSP   __attribute__((address_space(3)))    /* pointer known to address LDS: ds_* instead of flat_* */
 static HD int  hv_tid() { return (int)threadIdx.x; }
 static HD int  hv_shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 static HD int  hv_bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }   /* lane 0's value, wave-uniform (SGPR) */
@@ -68,12 +69,14 @@ static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
 #define HV_PROF_T0()  unsigned long long pt_ = __builtin_amdgcn_s_memtime()
 #define HV_PROF2_T0() unsigned long long p2_ = __builtin_amdgcn_s_memtime()
+#define HV_PROF3(S, ph) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof2[ph] += n_ - pt_; pt_ = n_; } } while (0)
 #define HV_PROF2(S, ph) do { if ((hv_tid() & 63) == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof2[ph] += n_ - p2_; p2_ = n_; } } while (0)
 #define HV_PROF(S, lvl, ph) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof[lvl][ph] += n_ - pt_; pt_ = n_; } } while (0)
 #else
 #define HV_PROF_T0() do { } while (0)
 #define HV_PROF2_T0() do { } while (0)
 #define HV_PROF2(S, ph) do { } while (0)
+#define HV_PROF3(S, ph) do { } while (0)
 #define HV_PROF(S, lvl, ph) do { } while (0)
 #endif
 
@@ -136,7 +139,7 @@ struct HvWaveScr {                                          /* private to one wa
     short scr[64 * 34];                                     /* [slot][row][N+2]: transposition buffer           */
     u8    pred[64 * 32];                                    /* [slot][row][N] prediction                        */
     u8    bord[672];                                        /* [slot][raw|smoothed][4N+4] reference samples     */
-    u8    crec[4096];                                       /* [slot][n][n] partial CU reconstruction (TU-split chains) */
+    u8    edge[256];                                        /* [slot][4][H] TU-split chains: right columns of sub-blocks 0,2 and bottom rows of 0,1 */
 };
 
 struct alignas(16) HvLds {
@@ -153,18 +156,20 @@ struct alignas(16) HvLds {
     u8  org[32][32];
     u8  rec[33][72];                                        /* row 0 = y-1, column HV_RX-1 = x-1; 64+1 columns used */
     u8  map_cu[9][12], map_pm[9][12];                       /* [1+i][1+j]; row 0 / column 0 = neighbours */
-    u8  line_rec[HEVCE_MAXDIM + 64];                        /* bottom row of the CTU row above */
     u8  line_cu[HEVCE_MAXDIM / 4];
-    int corner_next;
-    /* trials */
-    u8  tctx[HEVCE_NCTXP][HV_TL];
-    HevceCoderRegs tregs[HV_TL];
-    int tcost[HV_TL], tsse[HV_TL];
+    /* candidates ("trials") of the CU under evaluation at each level: 0 = 8x8, 1 = 16x16, 2 = 32x32.  A parent's
+       candidates are prepared at ITS entry and their arithmetic engines advance in slices during the children's phases. */
+    struct Level {
+        u8  tctx[HEVCE_NCTXP][HV_TL];                       /* context bytes, one column per candidate */
+        HevceCoderRegs tregs[HV_TL];
+        int tcost[HV_TL], tsse[HV_TL], tlen[HV_TL], tpos[HV_TL];
+        HvTuInfo tinfo[HV_TL][4];
+        u8  tdead[HV_TL];                                   /* abandoned: partial cost already above best_cost */
+        int best_cost;                                      /* lowest cost of a COMPLETED candidate (pruning bound) */
+        int quota;                                          /* tokens a parent candidate advances per child phase */
+        int split_inc, ml, ma;                              /* neighbour context read at the CU's entry [ref :1369-1373] */
+    } lv[3];
     u16 shdr[HV_TL][HEVCE_TOKEN_SLOTS + 2];                 /* slot headers, then (offset | g1 << 15) after linking */
-    int tlen[HV_TL];                                        /* tokens in each candidate's linked stream */
-    int best_cost;                                          /* lowest cost of a COMPLETED candidate of this CU (pruning bound) */
-    u8  tdead[HV_TL];                                       /* candidate abandoned: its partial cost already exceeded best_cost */
-    HvTuInfo tinfo[HV_TL][4];
     /* NxN sub-search */
     short nxn_lev[35][16];
     u8    nxn_rec[35][16];
@@ -357,10 +362,10 @@ static HD void hv_terminate(HvCod &c, int bin) {                                
 #define HV_HDR_G1      0x200
 #define HV_HDR_RESET   0x400
 
-struct HvTokW { u16 *p; int n; };
+template <typename P> struct HvTokW { P p; int n; };
 #define HV_SLOT_TOK0 8                      /* tokens start 16 bytes into the slot so that chunks of 8 load as one dwordx4 */
-static HD void hv_tok_ctx(HvTokW &w, int ctx, int bin) { w.p[HV_SLOT_TOK0 + w.n] = (u16)(ctx | (bin ? 0x80 : 0)); w.n++; }
-static HD void hv_tok_byp(HvTokW &w, int bins, int len) {                                                 /* [ref :899-911] */
+template <typename P> static HD void hv_tok_ctx(HvTokW<P> &w, int ctx, int bin) { w.p[HV_SLOT_TOK0 + w.n] = (u16)(ctx | (bin ? 0x80 : 0)); w.n++; }
+template <typename P> static HD void hv_tok_byp(HvTokW<P> &w, int bins, int len) {                                                 /* [ref :899-911] */
     bins &= (1 << len) - 1;
     while (len > 0) {
         const int n = hv_min(len, 8);
@@ -383,8 +388,8 @@ struct HvModes { int mode[4], left[4], above[4]; };
 
 /* CU header slot: split_cu_flag=0, part_mode, luma modes (all prev_intra_luma_pred_flags first, then mpm_idx /
    rem_intra_luma_pred_mode), chroma mode, split_transform_flag, cbf_cb, cbf_cr   [ref :943-1033, 1282-1287] */
-static HD int hv_tokenize_cu(u16 *slot, int n, int lg, int kind, int split_inc, const HvModes &pm) {
-    HvTokW w = { slot, 0 };
+template <typename P> static HD int hv_tokenize_cu(P slot, int n, int lg, int kind, int split_inc, const HvModes &pm) {
+    HvTokW<P> w = { slot, 0 };
     if (n >= 16) hv_tok_ctx(w, CX_SPLIT_CU + split_inc, 0);
     if (n == 8) hv_tok_ctx(w, CX_PART, kind != 2);
     const int parts = kind == 2 ? 4 : 1;
@@ -423,8 +428,8 @@ static HD int hv_tokenize_cu(u16 *slot, int n, int lg, int kind, int split_inc, 
 
 /* TU header slot: cbf_luma (unless the caller is the NxN sub-search, which codes bare residuals) and the position of
    the last significant coefficient   [ref :1038-1087, 1192] */
-static HD int hv_tokenize_tu(const HvLds &S, u16 *slot, int n, int lg, int kind_scan, int with_cbf, int cbf_ctx, int cbf, int last) {
-    HvTokW w = { slot, 0 };
+template <typename P> static HD int hv_tokenize_tu(const HvLds &S, P slot, int n, int lg, int kind_scan, int with_cbf, int cbf_ctx, int cbf, int last) {
+    HvTokW<P> w = { slot, 0 };
     if (with_cbf) hv_tok_ctx(w, cbf_ctx, cbf);
     if (cbf || !with_cbf) {
         int gy, gx, iy, ix;
@@ -459,7 +464,7 @@ static HD int hv_sigctx(int n, int diag, int y, int x, int nb) {                
     return base + 2;
 }
 
-static HD void hv_tok_remainder(HvTokW &w, int v, int k) {                                                 /* [ref :1154-1169] */
+template <typename P> static HD void hv_tok_remainder(HvTokW<P> &w, int v, int k) {                                                 /* [ref :1154-1169] */
     if (v < (3 << k)) {
         const int pre = v >> k;
         hv_tok_byp(w, (1 << (pre + 1)) - 2, pre + 1);
@@ -477,8 +482,8 @@ static HD void hv_tok_remainder(HvTokW &w, int v, int k) {                      
 /* one 4x4 coefficient group of a transform block whose levels lie in SCAN ORDER at lev16[0..15]   [ref :1194-1268]
    cg = the group's index in scan order; last / cgsig describe the whole block (from the TU job).
    Every loop below has a fixed trip count with predication, so that threads binarising different groups stay converged. */
-static HD int hv_tokenize_cg(const HvLds &S, u16 *slot, const short *lev16, int n, int lg, int kind, int cg, int last, u64 cgsig) {
-    HvTokW w = { slot, 0 };
+template <typename P, typename LP> static HD int hv_tokenize_cg(const HvLds &S, P slot, LP lev16, int n, int lg, int kind, int cg, int last, u64 cgsig) {
+    HvTokW<P> w = { slot, 0 };
     const int cg_last = last >> 4;
     int hdr = 0;
     if (cg <= cg_last) {
@@ -567,7 +572,8 @@ static HD int hv_link_token(int tok, int g1) {
     return (idx * HV_TL) | (((tok >> 7) & 1) << 14);
 }
 
-/* The arithmetic engine of one candidate over its linked stream of ntok tokens (chunk pointer, 16-byte aligned).
+/* The arithmetic engine of one candidate over tokens [i0, i1) of its linked stream (chunk pointer, 16-byte aligned);
+   resumable: the coder registers and the position are all the state there is.
    cx = &S.tctx[0][trial].  All lanes of a wavefront run this loop in lockstep; one iteration = one token through the
    same straight-line code for context-coded bins and bypass chunks; the next 8-token chunk is requested 8 tokens ahead.
    Pruning (exact): a candidate's cost w1*sse + w2*bits only grows while it is being encoded, so once its partial cost
@@ -575,10 +581,10 @@ static HD int hv_link_token(int tok, int g1) {
    arg-min, which is the LAST candidate of MINIMAL cost (ref :1440 adopts on >=).  Returns 1 when abandoned.
    [ref CABACputBin / CABACputBins :899-933] */
 template <typename ChunkPtr>
-static HD int hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int ntok, int q = 0, int sse = 0, int bits0 = 0, const int *best = nullptr) {
-    HvChunk cur = sp[0], nxt = sp[1];
-    for (int i = 0; i < ntok; i++) {
-        if ((i & 7) == 0 && i) { cur = nxt; nxt = sp[(i >> 3) + 1]; }
+static HD int hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int i0, int i1, int q = 0, int sse = 0, int bits0 = 0, const int *best = nullptr) {
+    HvChunk cur = sp[i0 >> 3], nxt = sp[(i0 >> 3) + 1];
+    for (int i = i0; i < i1; i++) {
+        if ((i & 7) == 0 && i != i0) { cur = nxt; nxt = sp[(i >> 3) + 1]; }
         const int tok = hv_chunk_get(cur, i & 7);
         const int isb = (tok >> 15) & 1;
         const int nb = (tok >> 8) & 15, bv = tok & 0xff;
@@ -660,10 +666,18 @@ template <> struct HvTm<32> { static HD const int *f() { return hv_tm.f32; } sta
 
 struct HvTuOut { int sse, last, cbf; u64 cgsig; };          /* block-wide values, identical in all lanes of a slot */
 
-/* reconstructed sample at CTU-relative (yy,xx): inside the CU under trial it comes from `inner` */
-static HD int hv_px(const HvLds &S, const u8 *inner, int cu_y, int cu_x, int cu_n, int yy, int xx) {
-    if (inner && yy >= cu_y && yy < cu_y + cu_n && xx >= cu_x && xx < cu_x + cu_n)
-        return inner[(yy - cu_y) * cu_n + (xx - cu_x)];
+/* reconstructed sample at CTU-relative (yy,xx).  Inside the CU under trial it comes from the candidate's own partial
+   reconstruction: `inner` is either the full cu_n x cu_n block (NxN sub-search) or, when `edges` is set, the chain's edge
+   store [4][H]: right columns of sub-blocks 0 and 2, bottom rows of sub-blocks 0 and 1 -- the only inner samples a later
+   sub-block ever reads (they all lie on row H-1 or column H-1 of the CU). */
+static HD int hv_px(const HvLds &S, const HV_LDSP u8 *inner, int edges, int cu_y, int cu_x, int cu_n, int yy, int xx) {
+    if (inner && yy >= cu_y && yy < cu_y + cu_n && xx >= cu_x && xx < cu_x + cu_n) {
+        const int ry = yy - cu_y, rx = xx - cu_x;
+        if (!edges) return inner[ry * cu_n + rx];
+        const int h = cu_n >> 1;
+        if (rx == h - 1) return inner[(ry < h ? 0 : 1) * h + (ry & (h - 1))];          /* right column of sub-block 0 / 2 */
+        return inner[(2 + (rx < h ? 0 : 1)) * h + (rx & (h - 1))];                       /* bottom row of sub-block 0 / 1   */
+    }
     return S.rec[yy + 1][xx + HV_RX];
 }
 /* which (size, mode) pairs read the smoothed reference samples  [ref HEVCe.c:274-280] */
@@ -674,14 +688,15 @@ static HD int hv_smoothed(int n, int m) {
     return n == 8 ? d > 7 : n == 16 ? d > 1 : d > 0;
 }
 
-template <int N>
+template <int N, typename LevP, typename RecP>
 static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
                             int ty, int tx,                         /* block origin, CTU-relative            */
-                            int cu_y, int cu_x, int cu_n, const u8 *inner,
+                            int cu_y, int cu_x, int cu_n, const HV_LDSP u8 *inner, int edges,
                             int aL, int aLB, int aA, int aAR,       /* neighbour availability                */
                             int mode,                               /* this slot's mode, or -1 (idle slot)   */
-                            short *lev_dst,                         /* N*N levels in scan order (per slot)   */
-                            u8 *rec_dst, int rec_stride) {          /* reconstruction (per slot)             */
+                            LevP lev_dst,                           /* N*N levels in scan order (per slot)   */
+                            RecP rec_dst, int rec_stride,           /* reconstruction (per slot)             */
+                            HV_LDSP u8 *ecol = nullptr, HV_LDSP u8 *erow = nullptr) {   /* chains: this block's right column / bottom row */
     HvLds &S = HV_S;
     HvWaveScr &W = S.ws[hv_uni(wave)];
     q = hv_uni(q); ty = hv_uni(ty); tx = hv_uni(tx); cu_y = hv_uni(cu_y); cu_x = hv_uni(cu_x); cu_n = hv_uni(cu_n);
@@ -696,17 +711,17 @@ static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
     /* ---- reference samples  [ref HEVCe.c:196-257] ---- */
     {
         int corner;
-        if (aL && aA)  corner = hv_px(S, inner, cu_y, cu_x, cu_n, ty - 1, tx - 1);
-        else if (aL)   corner = hv_px(S, inner, cu_y, cu_x, cu_n, ty, tx - 1);
-        else if (aA)   corner = hv_px(S, inner, cu_y, cu_x, cu_n, ty - 1, tx);
+        if (aL && aA)  corner = hv_px(S, inner, edges, cu_y, cu_x, cu_n, ty - 1, tx - 1);
+        else if (aL)   corner = hv_px(S, inner, edges, cu_y, cu_x, cu_n, ty, tx - 1);
+        else if (aA)   corner = hv_px(S, inner, edges, cu_y, cu_x, cu_n, ty - 1, tx);
         else           corner = 128;
-        const int l0 = aL ? hv_px(S, inner, cu_y, cu_x, cu_n, ty + j, tx - 1) : corner;
-        const int a0 = aA ? hv_px(S, inner, cu_y, cu_x, cu_n, ty - 1, tx + j) : corner;
+        const int l0 = aL ? hv_px(S, inner, edges, cu_y, cu_x, cu_n, ty + j, tx - 1) : corner;
+        const int a0 = aA ? hv_px(S, inner, edges, cu_y, cu_x, cu_n, ty - 1, tx + j) : corner;
         int l1, a1;
-        if (aLB) l1 = hv_px(S, inner, cu_y, cu_x, cu_n, ty + N + j, tx - 1);
-        else     l1 = aL ? hv_px(S, inner, cu_y, cu_x, cu_n, ty + N - 1, tx - 1) : corner;
-        if (aAR) a1 = hv_px(S, inner, cu_y, cu_x, cu_n, ty - 1, tx + N + j);
-        else     a1 = aA ? hv_px(S, inner, cu_y, cu_x, cu_n, ty - 1, tx + N - 1) : corner;
+        if (aLB) l1 = hv_px(S, inner, edges, cu_y, cu_x, cu_n, ty + N + j, tx - 1);
+        else     l1 = aL ? hv_px(S, inner, edges, cu_y, cu_x, cu_n, ty + N - 1, tx - 1) : corner;
+        if (aAR) a1 = hv_px(S, inner, edges, cu_y, cu_x, cu_n, ty - 1, tx + N + j);
+        else     a1 = aA ? hv_px(S, inner, edges, cu_y, cu_x, cu_n, ty - 1, tx + N - 1) : corner;
         if (j == 0) braw[0] = (u8)corner;
         braw[1 + j] = (u8)l0; braw[1 + N + j] = (u8)l1;
         braw[1 + 2 * N + j] = (u8)a0; braw[1 + 3 * N + j] = (u8)a1;
@@ -878,6 +893,8 @@ static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
             const int d = (int)S.org[ty + j][tx + x] - r;
             sse += d * d;
             if (mode >= 0) rec_dst[j * rec_stride + x] = (u8)r;
+            if (ecol && x == N - 1) ecol[j] = (u8)r;
+            if (erow && j == N - 1) erow[x] = (u8)r;
         }
     }
     for (int s = 1; s < N; s <<= 1) sse += hv_shfl_xor(sse, s);
@@ -896,54 +913,58 @@ static HD void hv_sub_avail(int s, int L, int LB, int A, int AR, int &l, int &lb
     ar = (s == 0) ? A : (s == 1 ? AR : (s == 2 ? 1 : 0));
 }
 
+typedef HV_GLOBAL short *HvGLev;   typedef HV_GLOBAL u8 *HvGRec;      /* trial scratch in HBM */
+typedef HV_LDSP short *HvLLev;     typedef HV_LDSP u8 *HvLRec;        /* wave / NxN staging in LDS */
 struct HvCu { int y, x, n, lg, lvl, L, LB, A, AR; };         /* CTU-relative CU under evaluation; lvl = lg-3 */
 
 /* step 2 jobs: one TU of the CU size  [ref HEVCe.c:1422-1432] */
 template <int N>
-static HDN void hv_job_single(int wave, int lane, int q, HvCu cu, int grp, short *glev, u8 *grec) {
+static HDN void hv_job_single(int wave, int lane, int q, HvCu cu, int grp, HvGLev glev, HvGRec grec) {
     HvLds &S = HV_S;
+    HvLds::Level &L = S.lv[hv_uni(cu.lvl)];
     grp = hv_uni(grp);
     const int slot = lane / N, j = lane % N;
     const int mode = grp * (64 / N) + slot;
     const bool ok = mode < HEVCE_NMODES;
-    HvTuOut o = hv_tu_job<N>(wave, lane, q, cu.y, cu.x, cu.y, cu.x, cu.n, nullptr, cu.L, cu.LB, cu.A, cu.AR,
+    HvTuOut o = hv_tu_job<N, HvGLev, HvGRec>(wave, lane, q, cu.y, cu.x, cu.y, cu.x, cu.n, nullptr, 0, cu.L, cu.LB, cu.A, cu.AR,
                              ok ? mode : -1, glev + (ok ? mode : HV_TL - 1) * 1024, grec + (ok ? mode : HV_TL - 1) * 1024, N);
     if (ok && j == 0) {
-        S.tsse[mode] = o.sse;
-        S.tinfo[mode][0].cgsig = o.cgsig; S.tinfo[mode][0].last = o.last; S.tinfo[mode][0].cbf = o.cbf;
+        L.tsse[mode] = o.sse;
+        L.tinfo[mode][0].cgsig = o.cgsig; L.tinfo[mode][0].last = o.last; L.tinfo[mode][0].cbf = o.cbf;
     }
 }
-/* step 3 jobs: four TUs of half the CU size, each predicted from the previous ones' reconstruction  [ref :1455-1468] */
+/* step 3 jobs: four TUs of half the CU size, each predicted from the previous ones' reconstruction  [ref :1455-1468].
+   The reconstruction goes straight to the candidate's HBM scratch; only the edge samples later sub-blocks read stay in LDS */
 template <int H>
-static HDN void hv_job_chain(int wave, int lane, int q, HvCu cu, int grp, short *glev, u8 *grec) {
+static HDN void hv_job_chain(int wave, int lane, int q, HvCu cu, int grp, HvGLev glev, HvGRec grec) {
     HvLds &S = HV_S;
+    HvLds::Level &L = S.lv[hv_uni(cu.lvl)];
     HvWaveScr &W = S.ws[hv_uni(wave)];
     grp = hv_uni(grp); cu.n = hv_uni(cu.n); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x);
     const int slot = lane / H, j = lane % H, n = cu.n;
     const int mode = grp * (64 / H) + slot;
     const bool ok = mode < HEVCE_NMODES;
     const int t = ok ? 35 + mode : HV_TL - 1;          /* idle slots aim at the unused pad trial */
-    u8 *crec = W.crec + slot * n * n;
+    HV_LDSP u8 *edge = (HV_LDSP u8 *)(W.edge + slot * 4 * H);
     int total = 0;
     for (int s = 0; s < 4; s++) {
         int l, lb, a, ar;
         hv_sub_avail(s, cu.L, cu.LB, cu.A, cu.AR, l, lb, a, ar);
         const int oy = (s >> 1) * H, ox = (s & 1) * H;
-        HvTuOut o = hv_tu_job<H>(wave, lane, q, cu.y + oy, cu.x + ox, cu.y, cu.x, n, crec, l, lb, a, ar,
-                                 ok ? mode : -1, glev + t * 1024 + s * H * H, crec + oy * n + ox, n);
+        HV_LDSP u8 *ecol = (s == 0) ? edge : (s == 2 ? edge + H : nullptr);
+        HV_LDSP u8 *erow = (s == 0) ? edge + 2 * H : (s == 1 ? edge + 3 * H : nullptr);
+        HvTuOut o = hv_tu_job<H, HvGLev, HvGRec>(wave, lane, q, cu.y + oy, cu.x + ox, cu.y, cu.x, n, edge, 1, l, lb, a, ar,
+                                 ok ? mode : -1, glev + t * 1024 + s * H * H, grec + t * 1024 + oy * n + ox, n, ecol, erow);
         total += o.sse;
-        if (ok && j == 0) { S.tinfo[t][s].cgsig = o.cgsig; S.tinfo[t][s].last = o.last; S.tinfo[t][s].cbf = o.cbf; }
+        if (ok && j == 0) { L.tinfo[t][s].cgsig = o.cgsig; L.tinfo[t][s].last = o.last; L.tinfo[t][s].cbf = o.cbf; }
     }
-    if (ok) {
-        if (j == 0) S.tsse[t] = total;
-        for (int r = j; r < n; r += H)                      /* publish the whole CU reconstruction of this candidate */
-            for (int x = 0; x < n; x++) grec[t * 1024 + r * n + x] = crec[r * n + x];
-    }
+    if (ok && j == 0) L.tsse[t] = total;
     WAVE_SYNC();
 }
 /* NxN job (8x8 CU only): per 4x4 sub-block choose the mode with a fresh coder and fresh contexts  [ref :1499-1528] */
 static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
     HvLds &S = HV_S;
+    HvLds::Level &L = S.lv[0];
     q = hv_uni(q); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x);
     const int slot = lane >> 2, j = lane & 3;
     int total = 0;
@@ -953,20 +974,19 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
         hv_sub_avail(s, cu.L, cu.LB, cu.A, cu.AR, l, lb, a, ar);
         const int oy = (s >> 1) * 4, ox = (s & 1) * 4;
         for (int g = 0; g < 3; g++) {
-            HV_TRACE(S, 5, s * 100 + g * 10 + 1);
             const int mode = g * 16 + slot;
             const bool ok = mode < HEVCE_NMODES;
-            HvTuOut o = hv_tu_job<4>(wave, lane, q, cu.y + oy, cu.x + ox, cu.y, cu.x, 8, &S.nxn_crec[0][0], l, lb, a, ar,
-                                     ok ? mode : -1, S.nxn_lev[ok ? mode : 0], S.nxn_rec[ok ? mode : 0], 4);
+            HvTuOut o = hv_tu_job<4, HvLLev, HvLRec>(wave, lane, q, cu.y + oy, cu.x + ox, cu.y, cu.x, 8, (HvLRec)&S.nxn_crec[0][0], 0, l, lb, a, ar,
+                                     ok ? mode : -1, (HvLLev)S.nxn_lev[ok ? mode : 0], (HvLRec)S.nxn_rec[ok ? mode : 0], 4);
             if (ok && j == 0) { S.nxn_sse[mode] = o.sse; S.nxn_last[mode] = o.last; S.nxn_sig[mode] = o.cbf; }
         }
         WAVE_SYNC();
-        HV_TRACE(S, 5, s * 100 + 50);
         HV_PROF2(S, 0);
-        /* rate of every candidate: lane = mode  [ref :1505-1519]; residual_coding is written even for an all-zero block */
+        /* rate of every candidate: lane = mode  [ref :1505-1519]; residual_coding is written even for an all-zero block.
+           The 8x8 level's context columns are free at this point (they are re-initialised before its engine phase). */
         int cost = HV_I32MAX, idx = -1;
         if (lane < HEVCE_NMODES) {
-            u8 *cx = &S.tctx[0][lane];
+            u8 *cx = &L.tctx[0][lane];
             for (int k = 0; k < 3; k++) { *HV_CX(CX_LASTX + k) = S.ctx_fresh[CX_LASTX + k]; *HV_CX(CX_LASTY + k) = S.ctx_fresh[CX_LASTY + k]; }
             for (int k = 0; k < 9; k++) *HV_CX(CX_SIG + k) = S.ctx_fresh[CX_SIG + k];
             for (int k = 0; k < 4; k++) *HV_CX(CX_ONE + k) = S.ctx_fresh[CX_ONE + k];
@@ -974,39 +994,36 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
             *HV_CX(HEVCE_NCTXP - 1) = 0;                          /* pad context used by bypass / no-op tokens */
             HvCod c;
             hv_cod_fresh(c);
-            u16 *tk = S.nxn_tok[lane];
+            HV_LDSP u16 *tk = (HV_LDSP u16 *)S.nxn_tok[lane];
             const int ks = hv_scan_kind(4, lane);
             /* the two slots are laid out so that their tokens are contiguous from tk[8]; one group: no set memory */
             const int na = hv_tokenize_tu(S, tk, 4, 2, ks, 0, 0, 1, S.nxn_last[lane]) & 0xff;
-            const int nb = hv_tokenize_cg(S, tk + na, S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0)) & 0xff;
+            const int nb = hv_tokenize_cg(S, tk + na, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0)) & 0xff;
             for (int k = 0; k < na + nb; k++) tk[HV_SLOT_TOK0 + k] = (u16)hv_link_token(tk[HV_SLOT_TOK0 + k], 0);
             HV_PROF2(S, 1);
-            hv_engine(S, c, cx, (const HvChunk *)(tk + HV_SLOT_TOK0), na + nb);
+            hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), 0, na + nb);
             cost = hv_rdcost(q, S.nxn_sse[lane], hv_cod_bits(c));
             idx = lane;
         }
         HV_PROF2(S, 2);
-        HV_TRACE(S, 5, s * 100 + 60);
         for (int sft = 1; sft < 64; sft <<= 1) {             /* minimum cost, the LATER mode wins ties  [ref :1521] */
             const int oc = hv_shfl_xor(cost, sft), oi = hv_shfl_xor(idx, sft);
             if (oc < cost || (oc == cost && oi > idx)) { cost = oc; idx = oi; }
         }
         const int w = idx;
-        HV_TRACE(S, 5, s * 100 + 70);
-        HV_TRACE(S, 6, w);
         if (lane < 16) {
             S.nxn_crec[oy + (lane >> 2)][ox + (lane & 3)] = S.nxn_rec[w][lane];
             S.nxn_bestlev[s][lane] = S.nxn_lev[w][lane];
         }
         if (lane == 0) {
             S.nxn_modes[s] = w;
-            S.tinfo[70][s].last = S.nxn_last[w]; S.tinfo[70][s].cbf = S.nxn_sig[w]; S.tinfo[70][s].cgsig = (u64)(S.nxn_sig[w] ? 1 : 0);
+            L.tinfo[70][s].last = S.nxn_last[w]; L.tinfo[70][s].cbf = S.nxn_sig[w]; L.tinfo[70][s].cgsig = (u64)(S.nxn_sig[w] ? 1 : 0);
         }
         total += S.nxn_sse[w];
         WAVE_SYNC();
         HV_PROF2(S, 3);
     }
-    if (lane == 0) S.tsse[70] = total;
+    if (lane == 0) L.tsse[70] = total;
 }
 /* distortion of the CU as currently reconstructed (the "split into four CUs" alternative)  [ref :1409] */
 static HD void hv_job_sse(HvLds &S, int lane, const HvCu &cu) {
@@ -1031,101 +1048,95 @@ static HD void hv_commit_bin(HvLds &S, int ctx, int bin) {
 }
 
 /* --------------------------------------------------------------------------------------------- */
-/* evaluation of one CU: TU jobs -> trial encodes -> arg-min -> commit   [ref HEVCe.c:1350-1560]    */
+/* evaluation of one CU  [ref HEVCe.c:1350-1560] in three steps:                                    */
+/*   hv_prepare_cu : at the CU's ENTRY (its entry coder state and outside neighbours are all the     */
+/*                   non-split candidates depend on): TU jobs, binarisation, linking, engine state   */
+/*   hv_engine_phase: arithmetic engines; 8x8 candidates run to completion, 16x16 / 32x32 candidates */
+/*                   advance by a quota of tokens, i.e. are time-sliced over their children's phases */
+/*   hv_decide_cu  : split alternative, arg-min (last of minimum), commit                            */
 /* --------------------------------------------------------------------------------------------- */
-static HD void hv_eval_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HevceRecord *rec, int32_t *dump) {
+static HD HV_GLOBAL u8 *hv_level_scratch(const HevceImageDesc &im, int lvl) { return (HV_GLOBAL u8 *)(im.scratch + (size_t)lvl * HEVCE_SCRATCH_LEVEL_BYTES); }
+static HD int hv_trial_slots(int n, int t) { const int tn = t < 35 ? n : (n >> 1); return 1 + (t < 35 ? 1 : 4) * (1 + (tn >> 2) * (tn >> 2)); }
+
+static HD void hv_prepare_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, n = cu.n;
-    short *glev = (short *)im.scratch;
-    u8 *grec = im.scratch + HV_TL * 1024 * 2;
+    HvLds::Level &L = S.lv[cu.lvl];
+    HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
+    HvGLev glev = (HvGLev)scr;
+    HvGRec grec = (HvGRec)(scr + HV_TL * 1024 * 2);
+    HV_GLOBAL u16 *gtok = (HV_GLOBAL u16 *)(scr + HV_TL * 1024 * 3);
+    HV_GLOBAL u16 *gstream = gtok + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT;
     const int ntrials = (n == 8) ? 71 : 70;
-    const int njobs = (n == 8) ? 9 : (n == 16) ? 15 : 28;
+    const int njobs = (n == 8) ? 9 : (n == 16) ? 14 : 27;
 
     /* neighbour context, read at CU entry  [ref :1369-1373] */
     const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
     const int split_inc = (n > S.map_cu[my][mx - 1]) + (n > S.map_cu[my - 1][mx]);
     const int ml = S.map_pm[my][mx - 1], ma = S.map_pm[my - 1][mx];
-
-    HV_TRACE(S, 1, cu.y * 1000 + cu.x * 10 + cu.lvl);
-    HV_TRACE(S, 2, 100);
+    if (tid == 0) { L.split_inc = split_inc; L.ml = ml; L.ma = ma; L.best_cost = HV_I32MAX; }
+    if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = 0; L.tlen[tid] = 0; }
     for (int k = tid; k < 8 * 8; k += HV_NTHREADS) (&S.nxn_crec[0][0])[k] = 0;
     BLOCK_SYNC();
     HV_PROF_T0();
 
     /* ---------------- TU jobs: static round-robin over the wavefronts, longest jobs first ----------------
-       (job ids are ordered by cost; rounds alternate direction so that the wave with the longest job gets the
-       fewest extra ones).  Everything controlling this loop is wave-uniform and lives in SGPRs: no lane-dependent
-       control flow may surround the calls, the jobs use wave-level shuffles. */
+       Everything controlling this loop is wave-uniform and lives in SGPRs: no lane-dependent control flow may surround
+       the calls, the jobs use wave-level shuffles. */
     {
         const int wv = hv_uni(wave), nj = hv_uni(njobs), nn = hv_uni(n);
-#ifdef HEVCE_SERIAL_JOBS
-        for (int job = 0; job < nj && wv == 0; job++) {
-#else
         for (int round = 0; round * HV_NWAVES < nj; round++) {
             const int job = round * HV_NWAVES + ((round & 1) ? HV_NWAVES - 1 - wv : wv);
             if (job >= nj) continue;
-#endif
-            HV_TRACE(S, 3, job);
             if (nn == 8) {
                 if (job == 0) hv_job_nxn(wave, lane, q, cu);
                 else if (job < 4) hv_job_chain<4>(wave, lane, q, cu, job - 1, glev, grec);
                 else hv_job_single<8>(wave, lane, q, cu, job - 4, glev, grec);
             } else if (nn == 16) {
                 if (job < 5) hv_job_chain<8>(wave, lane, q, cu, job, glev, grec);
-                else if (job < 14) hv_job_single<16>(wave, lane, q, cu, job - 5, glev, grec);
-                else hv_job_sse(S, lane, cu);
+                else hv_job_single<16>(wave, lane, q, cu, job - 5, glev, grec);
             } else {
                 if (job < 9) hv_job_chain<16>(wave, lane, q, cu, job, glev, grec);
-                else if (job < 27) hv_job_single<32>(wave, lane, q, cu, job - 9, glev, grec);
-                else hv_job_sse(S, lane, cu);
+                else hv_job_single<32>(wave, lane, q, cu, job - 9, glev, grec);
             }
         }
     }
-    HV_TRACE(S, 2, 200);
-    BLOCK_SYNC();                                               /* the NxN job borrows trial context columns */
+    BLOCK_SYNC();                                               /* the NxN job borrows the 8x8 level's context columns */
     HV_PROF(S, cu.lvl, 0);
-    if (tid == 0) S.best_cost = (n > 8) ? hv_rdcost(q, S.split_sse, hv_regs_bits(S.com) - hv_regs_bits(S.ent[cu.lvl])) : HV_I32MAX;   /* [ref :1410] */
-    if (tid < HV_TL) S.tdead[tid] = 0;
-    /* trial contexts start from the CU's entry snapshot  [ref :1423-1424] */
-    for (int k = tid; k < HEVCE_NCTXP * HV_TL; k += HV_NTHREADS) S.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[cu.lvl][k / HV_TL];
-    BLOCK_SYNC();
+    /* candidates start from the CU's entry snapshot  [ref :1423-1424] */
+    for (int k = tid; k < HEVCE_NCTXP * HV_TL; k += HV_NTHREADS) L.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[cu.lvl][k / HV_TL];
+    if (tid < ntrials) L.tregs[tid] = S.ent[cu.lvl];
 
-    HV_PROF(S, cu.lvl, 1);
-    HV_TRACE(S, 2, 300);
     /* ---------------- binarisation: one work item per slot of every candidate (data-parallel) ----------------
-       [ref :1434-1435, 1470-1471, 1540-1541 call the syntax writers per candidate; here only their bins are formed] */
-    u16 *gtok = (u16 *)(im.scratch + HV_TL * 1024 * 3);
+       [ref :1434-1435, 1470-1471, 1540-1541 call the syntax writers per candidate; here only their bins are formed]
+       slot f of candidate t: f = 0 CU header; then per transform block (1 for candidates 0..34, 4 otherwise) a header slot
+       followed by its 4x4 groups from the highest scan index down -- the order the engine consumes them.  Work items are
+       dense and grouped by kind so that the threads of a wavefront execute the same binarisation path. */
     {
-        /* slot f of candidate t: f = 0 CU header; then per transform block (1 for candidates 0..34, 4 otherwise) a header
-           slot followed by its 4x4 groups from the highest scan index down -- the order the engine consumes them.
-           Work items are dense and grouped by kind (all group slots, then block headers, then CU headers) so that the
-           threads of a wavefront execute the same binarisation path. */
         const int h = n >> 1, ncg_cu = (n >> 2) * (n >> 2);
         for (int item = tid; item < ntrials * ncg_cu; item += HV_NTHREADS) {          /* 4x4 group slots */
             const int t = item / ncg_cu, gi = item % ncg_cu;
             const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
             const int tn = kind == 0 ? n : h, tlg = kind == 0 ? cu.lg : cu.lg - 1, ncgt = (tn >> 2) * (tn >> 2);
             const int tu = gi / ncgt, r = gi % ncgt, cg = ncgt - 1 - r;
-            u16 *slot = gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt) + 1 + r) * HV_SLOT;
-            if (hv_rdcost(q, S.tsse[t], 0) > S.best_cost) continue;                 /* cannot win: never encoded */
+            HV_GLOBAL u16 *slot = gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt) + 1 + r) * HV_SLOT;
             u16 &sh = S.shdr[t][1 + tu * (1 + ncgt) + 1 + r];
-            if (!S.tinfo[t][tu].cbf) { sh = 0; continue; }
+            if (!L.tinfo[t][tu].cbf) { sh = 0; continue; }
             const int md = kind == 0 ? t : kind == 1 ? t - 35 : S.nxn_modes[tu];
-            const short *lev = (kind == 2) ? &S.nxn_bestlev[tu][0] : glev + t * 1024 + tu * tn * tn;
-            sh = (u16)hv_tokenize_cg(S, slot, lev + cg * 16, tn, tlg, hv_scan_kind(tn, md), cg, S.tinfo[t][tu].last, S.tinfo[t][tu].cgsig);
+            if (kind == 2) sh = (u16)hv_tokenize_cg(S, slot, (const HV_LDSP short *)&S.nxn_bestlev[tu][0], tn, tlg, hv_scan_kind(tn, md), cg, L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig);
+            else sh = (u16)hv_tokenize_cg(S, slot, (const HV_GLOBAL short *)(glev + t * 1024 + tu * tn * tn + cg * 16), tn, tlg, hv_scan_kind(tn, md), cg, L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig);
         }
+        if (n == 8) HV_PROF3(S, 4);
         for (int item = tid; item < ntrials * 4; item += HV_NTHREADS) {               /* transform-block header slots */
             const int t = item >> 2, tu = item & 3;
             const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
             if (kind == 0 && tu > 0) continue;
-            if (hv_rdcost(q, S.tsse[t], 0) > S.best_cost) continue;
             const int tn = kind == 0 ? n : h, tlg = kind == 0 ? cu.lg : cu.lg - 1, ncgt = (tn >> 2) * (tn >> 2);
             const int md = kind == 0 ? t : kind == 1 ? t - 35 : S.nxn_modes[tu];
-            u16 *slot = gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt)) * HV_SLOT;
-            S.shdr[t][1 + tu * (1 + ncgt)] = (u16)hv_tokenize_tu(S, slot, tn, tlg, hv_scan_kind(tn, md), 1, kind == 0 ? CX_YCBF + 1 : CX_YCBF, S.tinfo[t][tu].cbf, S.tinfo[t][tu].last);
+            HV_GLOBAL u16 *slot = gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt)) * HV_SLOT;
+            S.shdr[t][1 + tu * (1 + ncgt)] = (u16)hv_tokenize_tu(S, slot, tn, tlg, hv_scan_kind(tn, md), 1, kind == 0 ? CX_YCBF + 1 : CX_YCBF, L.tinfo[t][tu].cbf, L.tinfo[t][tu].last);
         }
         for (int t = tid; t < ntrials; t += HV_NTHREADS) {                            /* CU header slots */
             const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
-            if (hv_rdcost(q, S.tsse[t], 0) > S.best_cost) continue;
             HvModes pm;
             for (int s4 = 0; s4 < 4; s4++) { pm.mode[s4] = 0; pm.left[s4] = 0; pm.above[s4] = 0; }
             pm.left[0] = ml; pm.above[0] = ma;
@@ -1141,95 +1152,116 @@ static HD void hv_eval_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, Hev
         }
     }
     BLOCK_SYNC();
+    if (n == 8) HV_PROF3(S, 5);
     /* ---------------- link: slot offsets and greater1-set memory per candidate, then one contiguous stream each -------- */
-    u16 *gstream = gtok + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT;
     for (int t = tid; t < ntrials; t += HV_NTHREADS) {
-        int off = 0;
-        if (!(hv_rdcost(q, S.tsse[t], 0) > S.best_cost)) {
-            const int tn = t < 35 ? n : (n >> 1);
-            const int nslots = 1 + (t < 35 ? 1 : 4) * (1 + (tn >> 2) * (tn >> 2));
-            int g1 = 0;
-            for (int f = 0; f < nslots; f++) {
-                const int hdr = S.shdr[t][f];
-                if (hdr & HV_HDR_RESET) g1 = 0;
-                S.shdr[t][f] = (u16)(off | (g1 << 15));
-                if (hdr & HV_HDR_NZ) g1 = (hdr & HV_HDR_G1) ? 1 : 0;
-                off += hdr & 0xff;
-            }
-            S.shdr[t][nslots] = (u16)off;
+        const int nslots = hv_trial_slots(n, t);
+        int off = 0, g1 = 0;
+        for (int f = 0; f < nslots; f++) {
+            const int hdr = S.shdr[t][f];
+            if (hdr & HV_HDR_RESET) g1 = 0;
+            S.shdr[t][f] = (u16)(off | (g1 << 15));
+            if (hdr & HV_HDR_NZ) g1 = (hdr & HV_HDR_G1) ? 1 : 0;
+            off += hdr & 0xff;
         }
-        S.tlen[t] = off;
+        S.shdr[t][nslots] = (u16)off;
+        L.tlen[t] = off;
     }
     BLOCK_SYNC();
-    for (int item = tid; item < ntrials * HV_SLOTS_TRIAL; item += HV_NTHREADS) {
-        const int t = item / HV_SLOTS_TRIAL, f = item % HV_SLOTS_TRIAL;
-        const int tn = t < 35 ? n : (n >> 1);
-        const int nslots = 1 + (t < 35 ? 1 : 4) * (1 + (tn >> 2) * (tn >> 2));
-        if (f >= nslots || S.tlen[t] == 0) continue;
-        const int o0 = S.shdr[t][f], off = o0 & 0x7fff, g1 = o0 >> 15, cnt = (S.shdr[t][f + 1] & 0x7fff) - off;
-        const HV_GLOBAL HvChunk *src = (const HV_GLOBAL HvChunk *)(gtok + (size_t)item * HV_SLOT + HV_SLOT_TOK0);
-        HV_GLOBAL u16 *dst = (HV_GLOBAL u16 *)(gstream + (size_t)t * HEVCE_STREAM_WORDS + off);
-        for (int k0 = 0; k0 < cnt; k0 += 8) {
-            const HvChunk ch = src[k0 >> 3];
-            for (int j = 0; j < 8; j++) if (k0 + j < cnt) dst[k0 + j] = (u16)hv_link_token(hv_chunk_get(ch, j), g1);
+    if (n == 8) HV_PROF3(S, 6);
+    /* copy: one wavefront per candidate walks its slots; lane k moves token k of the slot (coalesced 2-byte stores) */
+    for (int t = hv_uni(wave); t < ntrials; t += HV_NWAVES) {
+        const int nslots = hv_trial_slots(n, t);
+        HV_GLOBAL u16 *dst = gstream + (size_t)t * HEVCE_STREAM_WORDS;
+        const HV_GLOBAL u16 *src = gtok + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0;
+        for (int f = 0; f < nslots; f++) {
+            const int o0 = S.shdr[t][f], off = o0 & 0x7fff, g1 = o0 >> 15, cnt = (S.shdr[t][f + 1] & 0x7fff) - off;
+            for (int k = lane; k < cnt; k += 64) dst[off + k] = (u16)hv_link_token(src[f * HV_SLOT + k], g1);
         }
     }
+    if (tid == 0) {                                              /* slice size of a parent's candidates: done by its last child */
+        int mx_len = 0;
+        for (int t = 0; t < ntrials; t++) mx_len = hv_max(mx_len, L.tlen[t]);
+        const int phases = (n == 8) ? 1 : (n == 16 ? 4 : 16);
+        L.quota = (n == 8) ? 0x7fffffff : ((mx_len + phases - 1) / phases + 16);
+    }
     BLOCK_SYNC();
+    if (n == 8) HV_PROF3(S, 7);
     HV_PROF(S, cu.lvl, 5);
+}
 
-    /* ---------------- arithmetic engine: lane = candidate, all lanes in lockstep over their token streams ------------ */
-    {
-        const int t = lane * HV_NWAVES + wave;                  /* spread the candidates over all wavefronts */
-        if (lane < 9 && t < ntrials) {
+/* lanes 0..8 of every wavefront: 8x8 candidates; 9..17: 16x16; 18..26: 32x32 (candidate = lane' * 8 + wave).
+   mask: bit l set = level l takes part; `finish` lifts the quota (used when a parent is decided). */
+static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int finish) {
+    const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
+    HV_PROF_T0();
+    const int lvl = lane / 9, t = (lane % 9) * HV_NWAVES + wave;
+    if (lvl < 3 && ((mask >> lvl) & 1)) {
+        HvLds::Level &L = S.lv[lvl];
+        const int ntrials = (lvl == 0) ? 71 : 70;
+        if (t < ntrials && L.tpos[t] <= L.tlen[t]) {                       /* tpos == tlen + 1 marks finished / abandoned */
+            const int pos = L.tpos[t], len = L.tlen[t];
             HvCod c;
-            hv_cod_load(c, S.ent[cu.lvl]);
-            const int bits0 = hv_cod_bits(c);
-            int dead = hv_rdcost(q, S.tsse[t], 0) > S.best_cost;          /* same test the binarisation used (best_cost only changes below) */
-            if (!dead) dead = hv_engine(S, c, &S.tctx[0][t], (const HV_GLOBAL HvChunk *)(gstream + (size_t)t * HEVCE_STREAM_WORDS), S.tlen[t],
-                                        q, S.tsse[t], bits0, &S.best_cost);
-            const int cost = dead ? HV_I32MAX : hv_rdcost(q, S.tsse[t], hv_cod_bits(c) - bits0);
-            S.tcost[t] = cost;
-            S.tdead[t] = (u8)dead;
-            if (!dead) hv_atomic_min(&S.best_cost, cost);
-            hv_cod_store(S.tregs[t], c);
+            hv_cod_load(c, L.tregs[t]);
+            const int bits0 = hv_regs_bits(S.ent[lvl]);
+            const int end = (finish || lvl == 0) ? len : hv_min(len, pos + L.quota);
+            const HV_GLOBAL u16 *gstream = (const HV_GLOBAL u16 *)(hv_level_scratch(im, lvl) + HV_TL * 1024 * 3) + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT;
+            int dead = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0) > hv_peek(&L.best_cost);
+            if (!dead && pos < end)
+                dead = hv_engine(S, c, &L.tctx[0][t], (const HV_GLOBAL HvChunk *)(gstream + (size_t)t * HEVCE_STREAM_WORDS), pos, end,
+                                 q, L.tsse[t], bits0, &L.best_cost);
+            hv_cod_store(L.tregs[t], c);
+            if (dead) { L.tdead[t] = 1; L.tcost[t] = HV_I32MAX; L.tpos[t] = len + 1; }
+            else if (end == len) {
+                const int cost = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0);
+                L.tcost[t] = cost;
+                L.tpos[t] = len + 1;
+                hv_atomic_min(&L.best_cost, cost);
+            } else L.tpos[t] = end;
         }
     }
     BLOCK_SYNC();
+    HV_PROF(S, 0, 6);
+}
 
+static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HevceRecord *rec, int32_t *dump) {
+    const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, n = cu.n;
+    HvLds::Level &L = S.lv[cu.lvl];
+    HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
+    HvGLev glev = (HvGLev)scr;
+    HvGRec grec = (HvGRec)(scr + HV_TL * 1024 * 2);
+    const int ntrials = (n == 8) ? 71 : 70;
+    const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
+    HV_PROF_T0();
+    if (n > 8) {
+        /* the split alternative is the state the children left behind  [ref :1409-1410]; it also bounds the pruning */
+        if (hv_uni(wave) == 0) hv_job_sse(S, lane, cu);
+        BLOCK_SYNC();
+        if (tid == 0) hv_atomic_min(&L.best_cost, hv_rdcost(q, S.split_sse, hv_regs_bits(S.com) - hv_regs_bits(S.ent[cu.lvl])));
+        BLOCK_SYNC();
+        hv_engine_phase(S, im, 1 << cu.lvl, 1);                 /* whatever the slices left over */
+    }
     HV_PROF(S, cu.lvl, 2);
     if (dump && tid < HV_TL) {
         int32_t *d = dump + 16 * tid;
         const bool v = tid < ntrials;
-        d[0] = v ? S.tsse[tid] : 0; d[1] = v ? S.tcost[tid] : 0;
-        for (int s4 = 0; s4 < 4; s4++) {
-            d[2 + s4] = v ? S.tinfo[tid][s4].last * 2 + S.tinfo[tid][s4].cbf : 0;
-            d[6 + s4] = v ? (int)(S.tinfo[tid][s4].cgsig & 0xffffffffu) : 0;
-        }
-        d[10] = v ? S.tregs[tid].range : 0; d[11] = v ? (int)S.tregs[tid].low : 0; d[12] = v ? S.tregs[tid].nbits : 0; d[13] = v ? S.tregs[tid].nout : 0;
-        int h = 0;
-        if (v) for (int k = 0; k < HEVCE_NCTX; k++) h = h * 31 + S.tctx[k][tid];
-        d[14] = h;
-        int ck = 0;
-        if (v && tid < 70) for (int k = 0; k < n * n; k++) ck = ck * 131 + glev[tid * 1024 + k];
-        d[15] = ck;
+        d[0] = v ? L.tsse[tid] : 0; d[1] = v ? L.tcost[tid] : 0; d[2] = v ? L.tdead[tid] : 0; d[3] = v ? L.tlen[tid] : 0;
     }
-    HV_TRACE(S, 2, 400);
     /* ---------------- arg-min in the reference's order, later candidate wins ties ---------------- */
     if (tid == 0) {
         int best = HV_I32MAX, w = -1;
         if (n > 8) best = hv_rdcost(q, S.split_sse, hv_regs_bits(S.com) - hv_regs_bits(S.ent[cu.lvl]));
-        for (int t = 0; t < ntrials; t++) if (!S.tdead[t] && best >= S.tcost[t]) { best = S.tcost[t]; w = t; }
+        for (int t = 0; t < ntrials; t++) if (!L.tdead[t] && best >= L.tcost[t]) { best = L.tcost[t]; w = t; }
         S.winner = w;
     }
     BLOCK_SYNC();
     const int w = S.winner;
     HV_PROF(S, cu.lvl, 3);
-    HV_TRACE(S, 2, 500);
     if (w < 0) return;                                          /* the four sub-CUs stay */
 
     /* ---------------- commit the winner: coder, contexts, reconstruction, maps, record ---------------- */
-    if (tid == 0) S.com = S.tregs[w];
-    if (tid < HEVCE_NCTXP) S.com_ctx[tid] = S.tctx[tid][w];
+    if (tid == 0) S.com = L.tregs[w];
+    if (tid < HEVCE_NCTXP) S.com_ctx[tid] = L.tctx[tid][w];
     const int kindw = w < 35 ? 0 : (w < 70 ? 1 : 2);
     for (int p = tid; p < n * n; p += HV_NTHREADS) {
         const int yy = p / n, xx = p % n;
@@ -1282,7 +1314,7 @@ static HD void hv_init_tables(HvLds &S, int q, int tid) {
         const u8 v = (u8)(st >= 64 ? (((st - 64) << 1) | 1) : ((63 - st) << 1));
         S.ctx_fresh[i] = v; S.com_ctx[i] = v;
     }
-    if (tid == 300) { S.com.range = 510; S.com.low = 0; S.com.nbits = 23; S.com.nbytes = 0; S.com.bufbyte = 0xff; S.com.zeros = 0; S.com.nout = 0; S.com.pad = 0; S.corner_next = 128; }
+    if (tid == 300) { S.com.range = 510; S.com.low = 0; S.com.nbits = 23; S.com.nbytes = 0; S.com.bufbyte = 0xff; S.com.zeros = 0; S.com.nout = 0; S.com.pad = 0; }
 }
 
 static HD void hv_snapshot(HvLds &S, int lvl, int tid) {
@@ -1312,7 +1344,10 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
             }
             if (tid < 32) S.rec[1 + tid][HV_RX - 1] = L ? S.rec[1 + tid][HV_RX + 31] : 128;   /* left column = previous CTU's last column */
             BLOCK_SYNC();
-            if (tid < 65) S.rec[0][HV_RX - 1 + tid] = (tid == 0) ? (u8)S.corner_next : S.line_rec[x0 + tid - 1];
+            if (tid < 65 && A) {                                 /* row above (x0-1 .. x0+63) from the reconstruction in HBM */
+                const int xx = hv_min(hv_max(x0 + tid - 1, 0), W - 1);
+                S.rec[0][HV_RX - 1 + tid] = im.rcon[(size_t)(y0 - 1) * W + xx];
+            }
             if (tid >= 128 && tid < 136) {
                 const int i = tid - 128;
                 S.map_cu[1 + i][0] = L ? S.map_cu[1 + i][8] : 32;
@@ -1322,13 +1357,14 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
             if (tid >= 192 && tid < 201) {
                 const int jx = tid - 192;                        /* row above: CU sizes of the CTU row above, modes always DC */
                 S.map_cu[0][jx] = (A && (jx > 0 || L)) ? S.line_cu[(x0 >> 2) + jx - 1] : 32;
-                if (jx == 0 && !A) S.map_cu[0][0] = 32;
                 S.map_pm[0][jx] = 1;
             }
             for (int p = tid; p < (int)(sizeof(HevceRecord) / 4); p += HV_NTHREADS) ((int *)rec)[p] = 0;
             BLOCK_SYNC();
 
-            /* ---- quad-tree, depth first in z-order  [ref :1403-1407]: 21 CUs = 4 x (4 x 8x8, 16x16), 32x32 ---- */
+            /* ---- quad-tree, depth first in z-order  [ref :1403-1407]: 21 CUs = 4 x (4 x 8x8, 16x16), 32x32.
+               A CU's candidates are prepared when the CU is ENTERED (before its split_cu_flag / children), decided after
+               its children; parents' engines advance inside every 8x8 engine phase. ---- */
             const HvCu c32 = { 0, 0, 32, 5, 2, L, 0, A, AR };
             for (int step = 0; step < 21; step++) {
                 const int k = step / 5, m = step % 5;
@@ -1340,24 +1376,27 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     cu.y = c16.y + (m >> 1) * 8; cu.x = c16.x + (m & 1) * 8; cu.n = 8; cu.lg = 3; cu.lvl = 0;
                     hv_sub_avail(m, c16.L, c16.LB, c16.A, c16.AR, cu.L, cu.LB, cu.A, cu.AR);
                 }
-                if (step == 0) {                                 /* entering the 32x32 CU: snapshot, then split_cu_flag = 1 */
+                if (step == 0) {                                 /* entering the 32x32 CU */
                     hv_snapshot(S, 2, tid);
                     BLOCK_SYNC();
-                    if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + (32 > S.map_cu[1][0]) + (32 > S.map_cu[0][1]), 1);
+                    hv_prepare_cu(S, im, c32);
+                    if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + S.lv[2].split_inc, 1);
                     BLOCK_SYNC();
                 }
                 if (step < 20 && m == 0) {                       /* entering a 16x16 CU */
                     hv_snapshot(S, 1, tid);
                     BLOCK_SYNC();
-                    if (tid == 0) {
-                        const int my = 1 + (c16.y >> 2), mx = 1 + (c16.x >> 2);
-                        hv_commit_bin(S, CX_SPLIT_CU + (16 > S.map_cu[my][mx - 1]) + (16 > S.map_cu[my - 1][mx]), 1);
-                    }
+                    hv_prepare_cu(S, im, c16);
+                    if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + S.lv[1].split_inc, 1);
                     BLOCK_SYNC();
                 }
-                HV_TRACE(S, 4, step);
-                if (cu.n == 8) { hv_snapshot(S, 0, tid); BLOCK_SYNC(); }
-                hv_eval_cu(S, im, cu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr);
+                if (cu.n == 8) {
+                    hv_snapshot(S, 0, tid);
+                    BLOCK_SYNC();
+                    hv_prepare_cu(S, im, cu);
+                    hv_engine_phase(S, im, 7, 0);
+                }
+                hv_decide_cu(S, im, cu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr);
             }
 
             /* ---- end of CTU: terminate bin, publish reconstruction and line buffers  [ref :1626-1637] ---- */
@@ -1371,12 +1410,10 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     st[0] = c.range; st[1] = (int32_t)c.low; st[2] = c.nbits; st[3] = c.nbytes; st[4] = c.bufbyte; st[5] = c.zeros;
                     st[6] = c.nout; st[7] = hv_cod_bits(c);
                 }
-                S.corner_next = S.line_rec[x0 + 31];
             }
             for (int p = tid; p < 1024; p += HV_NTHREADS)
                 im.rcon[(size_t)(y0 + (p >> 5)) * W + x0 + (p & 31)] = S.rec[1 + (p >> 5)][HV_RX + (p & 31)];
             BLOCK_SYNC();
-            if (tid < 32) S.line_rec[x0 + tid] = S.rec[32][HV_RX + tid];
             if (tid >= 64 && tid < 72) S.line_cu[(x0 >> 2) + tid - 64] = S.map_cu[8][1 + tid - 64];
             BLOCK_SYNC();
         }

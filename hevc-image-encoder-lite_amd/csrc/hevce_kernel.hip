@@ -49,12 +49,12 @@ hevce_test_tu_kernel(const unsigned char *org /*32x32*/, const unsigned char *nb
         const int mode = grp * per + tid / n;
         const bool ok = mode < HEVCE_NMODES;
         HvTuOut o;
-        short *ld = lev + (ok ? mode : 0) * 1024;
-        unsigned char *rd = rec + (ok ? mode : 0) * 1024;
-        if (n == 4)       o = hv_tu_job<4>(0, tid, q, 0, 0, 0, 0, n, nullptr, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
-        else if (n == 8)  o = hv_tu_job<8>(0, tid, q, 0, 0, 0, 0, n, nullptr, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
-        else if (n == 16) o = hv_tu_job<16>(0, tid, q, 0, 0, 0, 0, n, nullptr, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
-        else              o = hv_tu_job<32>(0, tid, q, 0, 0, 0, 0, n, nullptr, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
+        HvGLev ld = (HvGLev)(lev + (ok ? mode : 0) * 1024);
+        HvGRec rd = (HvGRec)(rec + (ok ? mode : 0) * 1024);
+        if (n == 4)       o = hv_tu_job<4, HvGLev, HvGRec>(0, tid, q, 0, 0, 0, 0, n, nullptr, 0, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
+        else if (n == 8)  o = hv_tu_job<8, HvGLev, HvGRec>(0, tid, q, 0, 0, 0, 0, n, nullptr, 0, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
+        else if (n == 16) o = hv_tu_job<16, HvGLev, HvGRec>(0, tid, q, 0, 0, 0, 0, n, nullptr, 0, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
+        else              o = hv_tu_job<32, HvGLev, HvGRec>(0, tid, q, 0, 0, 0, 0, n, nullptr, 0, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
         if (ok && tid % n == 0) { info[mode * 4] = o.sse; info[mode * 4 + 1] = o.last; info[mode * 4 + 2] = o.cbf; info[mode * 4 + 3] = (int)(o.cgsig & 0xffffffffu); }
     }
 }
@@ -88,8 +88,8 @@ hevce_test_chain_kernel(const unsigned char *org, const unsigned char *nbr, int 
         }
     }
     __syncthreads();
-    short *glev = (short *)scratch;
-    u8 *grec = scratch + HV_TL * 1024 * 2;
+    HvGLev glev = (HvGLev)scratch;
+    HvGRec grec = (HvGRec)(scratch + HV_TL * 1024 * 2);
     HvCu cu = { 0, 0, n, n == 8 ? 3 : n == 16 ? 4 : 5, n == 8 ? 0 : n == 16 ? 1 : 2, aL, aLB, aA, aAR };
     const int per = 64 / (n / 2);
     for (int grp = 0; grp * per < HEVCE_NMODES; grp++) {
@@ -100,8 +100,9 @@ hevce_test_chain_kernel(const unsigned char *org, const unsigned char *nbr, int 
     __syncthreads();
     for (int m = tid; m < HEVCE_NMODES; m += 64) {
         int *d = info + m * 16;
-        d[0] = S.tsse[35 + m];
-        for (int s = 0; s < 4; s++) { d[1 + s] = S.tinfo[35 + m][s].last; d[5 + s] = S.tinfo[35 + m][s].cbf; d[9 + s] = (int)(S.tinfo[35 + m][s].cgsig & 0xffffffffu); }
+        const HvLds::Level &L = S.lv[cu.lvl];
+        d[0] = L.tsse[35 + m];
+        for (int s = 0; s < 4; s++) { d[1 + s] = L.tinfo[35 + m][s].last; d[5 + s] = L.tinfo[35 + m][s].cbf; d[9 + s] = (int)(L.tinfo[35 + m][s].cgsig & 0xffffffffu); }
     }
 }
 extern "C" int hevce_launch_test_chain(const unsigned char *org, const unsigned char *nbr, int n, int q, int aL, int aLB, int aA, int aAR,
