@@ -146,6 +146,8 @@ struct alignas(16) HvLds {
     /* tables (copied from constant memory so that per-lane divergent lookups are LDS reads) */
     unsigned lps4[64];
     u8  lpsnext[64];
+    u16 lpsq[256];                                          /* [state*4 + (range>>6 & 3)] = LPS range | renormalisation shift << 8 */
+    u8  nxt_mps[128], nxt_lps[128];                         /* context byte after an MPS / LPS  [ref HEVCe.c:701-702] */
     u8  d4pos[16], d4idx[16];                               /* diagonal scan inside a 4x4 group: idx->(y<<2|x), (y<<2|x)->idx */
     u8  cgpos[3][64], cgidx[3][64];                         /* group order for 2x2 / 4x4 / 8x8 groups: idx->(gy<<3|gx), gy*ncg+gx->idx */
     u8  ctx_fresh[HEVCE_NCTXP];
@@ -177,6 +179,8 @@ struct alignas(16) HvLds {
     short nxn_bestlev[4][16];
     alignas(16) u16 nxn_tok[35][144];                                 /* per candidate: its token stream (header + one group), 16-byte rows */
     u8    nxn_crec[8][8];
+    u8    nxn_line[35][16];                                 /* per mode: angular reference line r(-4..9) */
+    u8    nxn_bord[20];                                     /* raw reference samples of the current 4x4: corner, left[8], above[8] */
     int   nxn_modes[4];
     /* control */
     int winner, split_sse;
@@ -580,49 +584,42 @@ static HD int hv_link_token(int tok, int g1) {
    exceeds the cost of a candidate that has COMPLETED (or of the split alternative, known beforehand) it cannot be the
    arg-min, which is the LAST candidate of MINIMAL cost (ref :1440 adopts on >=).  Returns 1 when abandoned.
    [ref CABACputBin / CABACputBins :899-933] */
+/* one token through the coder: context-coded bin or bypass chunk, same straight-line code (table driven) */
+static HD void hv_engine_step(const HvLds &S, HvCod &c, u8 *cx, int tok) {
+    const int isb = (tok >> 15) & 1;
+    const int nb = (tok >> 8) & 15, bv = tok & 0xff;
+    u8 *cp = cx + (isb ? (HEVCE_NCTXP - 1) * HV_TL : (tok & 0x1fff));        /* bypass: pad context, written back unchanged */
+    const int cv = *cp & 0x7f;
+    const int e = S.lpsq[((cv & 0x7e) << 1) | ((c.range >> 6) & 3)];
+    const int nm = S.nxt_mps[cv], nl = S.nxt_lps[cv];
+    const int lps = e & 0xff, shl = e >> 8;
+    const int islps = (((tok >> 14) & 1) ^ cv) & 1;
+    const int rm = c.range - lps;
+    const int shm = (rm < 256) ? 1 : 0;
+    const unsigned low_c = islps ? ((c.low + (unsigned)rm) << shl) : (c.low << shm);
+    const int range_c = islps ? (lps << shl) : (rm << shm);
+    const int sh_c = islps ? shl : shm;
+    const unsigned low_b = (c.low << nb) + (unsigned)c.range * (unsigned)bv;
+    c.low = isb ? low_b : low_c;
+    c.range = isb ? c.range : range_c;
+    c.nbits -= isb ? nb : sh_c;
+    *cp = (u8)(isb ? cv : (islps ? nl : nm));
+    hv_cod_carry_fast(c);
+}
 template <typename ChunkPtr>
 static HD int hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int i0, int i1, int q = 0, int sse = 0, int bits0 = 0, const int *best = nullptr) {
-    HvChunk cur = sp[i0 >> 3], nxt = sp[(i0 >> 3) + 1];
-    for (int i = i0; i < i1; i++) {
-        if ((i & 7) == 0 && i != i0) { cur = nxt; nxt = sp[(i >> 3) + 1]; }
-        const int tok = hv_chunk_get(cur, i & 7);
-        const int isb = (tok >> 15) & 1;
-        const int nb = (tok >> 8) & 15, bv = tok & 0xff;
-        u8 *cp = cx + (isb ? (HEVCE_NCTXP - 1) * HV_TL : (tok & 0x1fff));        /* bypass: pad context, written back unchanged */
-#ifdef HEVCE_ABL_NOLDS
-        const int cv = (tok * 37) & 127, st = cv >> 1, mps = cv & 1;
-        const unsigned lw = 0x30405060u + st;
-        const int lnx = st >> 1;
-#else
-        const int cv = *cp, st = cv >> 1, mps = cv & 1;
-        const unsigned lw = S.lps4[st];
-        const int lnx = S.lpsnext[st];
-#endif
-        const int lps = (int)((lw >> (((c.range >> 6) & 3) << 3)) & 0xff);
-        const int islps = (((tok >> 14) & 1) ^ mps);
-        const int rm = c.range - lps;
-        const int shl = (lps < 8) ? 6 : hv_clz((unsigned)(lps >> 3)) - 26;
-        const int shm = (rm < 256) ? 1 : 0;
-        const int cvl = (st == 0) ? (mps ^ 1) : ((lnx << 1) | mps);
-        const int cvm = (st < 62) ? cv + 2 : cv;
-        const unsigned low_c = islps ? ((c.low + (unsigned)rm) << shl) : (c.low << shm);
-        const int range_c = islps ? (lps << shl) : (rm << shm);
-        const int sh_c = islps ? shl : shm;
-        const unsigned low_b = (c.low << nb) + (unsigned)c.range * (unsigned)bv;
-        c.low = isb ? low_b : low_c;
-        c.range = isb ? c.range : range_c;
-        c.nbits -= isb ? nb : sh_c;
-#ifndef HEVCE_ABL_NOLDS
-        *cp = (u8)(isb ? cv : (islps ? cvl : cvm));
-#else
-        c.zeros += (isb ? cv : (islps ? cvl : cvm)) & 1;
-#endif
-#ifndef HEVCE_ABL_NOCARRY
-        hv_cod_carry_fast(c);
-#else
-        if (c.nbits < 12) { c.nbits += 8; c.low &= 0xffffffffu >> c.nbits; c.nout++; }
-#endif
-        if (best && (i & 15) == 15 && hv_rdcost(q, sse, hv_cod_bits(c) - bits0) > hv_peek(best)) return 1;
+    if (i0 >= i1) return 0;
+    int base = i0 & ~7;
+    HvChunk nxt = sp[base >> 3];
+    for (; base < i1; base += 8) {
+        const HvChunk cur = nxt;
+        nxt = sp[(base >> 3) + 1];                                /* requested eight tokens ahead of its first use */
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = base + j;
+            if (i >= i0 && i < i1) hv_engine_step(S, c, cx, (int)((cur[j >> 1] >> ((j & 1) << 4)) & 0xffffu));
+        }
+        if (best && (base & 8) && hv_rdcost(q, sse, hv_cod_bits(c) - bits0) > hv_peek(best)) return 1;
     }
     return 0;
 }
@@ -631,25 +628,47 @@ static HD int hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int i0, i
 /* quantiser  [ref HEVCe.c:526-595]                                                                 */
 /* --------------------------------------------------------------------------------------------- */
 static HD int hv_level_rate(int lv) {                                                                      /* [ref :526-535] */
-    if (lv < 6) return lv == 0 ? 0 : lv == 1 ? 70000 : lv == 2 ? 90000 : lv == 3 ? 92000 : lv == 4 ? 157536 : 190304;
-    const int i = 31 - hv_clz((unsigned)(lv - 5));        /* Exp-Golomb prefix length of lv-6 */
-    return 92000 + ((4 + 2 * i) << 15);
+    /* lv < 6: table {0, 70000, 90000, 92000, 157536, 190304}; else 92000 + ((4 + 2*prefix_len(lv-6)) << 15) -- selects only */
+    const int i = 31 - hv_clz((unsigned)hv_max(lv - 5, 1));
+    const int big = 92000 + ((4 + 2 * i) << 15);
+    int r = lv == 0 ? 0 : 70000;
+    r = lv >= 2 ? 90000 : r;
+    r = lv >= 3 ? 92000 : r;
+    r = lv >= 4 ? 157536 : r;
+    r = lv >= 5 ? 190304 : r;
+    return lv >= 6 ? big : r;
 }
-/* returns the level magnitude; d = scaled magnitude used by the group zero-out test */
+/* RD cost with the per-qpd6 weights already selected (wd, wb) and their overflow guards (I32MAX / w)  [ref :177-185] */
+struct HvRd { int wd, wb, gd, gb; };
+static HD HvRd hv_rd_make(int q) {
+    HvRd r;
+    r.wd = (q < 3) ? 11 : (q == 3 ? 5 : 1);
+    r.wb = (q == 0) ? 1 : (q == 1) ? 4 : (q == 2) ? 16 : (q == 3) ? 29 : 23;
+    r.gd = HV_I32MAX / r.wd; r.gb = HV_I32MAX / r.wb;
+    return r;
+}
+static HD int hv_rd(const HvRd &w, int dist, int bits) {
+    const int a = (w.gd <= dist) ? HV_I32MAX : w.wd * dist;
+    const int b = (w.gb <= bits) ? HV_I32MAX : w.wb * bits;
+    return (HV_I32MAX - a <= b) ? HV_I32MAX : a + b;
+}
+/* returns the level magnitude; d = scaled magnitude used by the group zero-out test.  Three candidates (level, level-1,
+   level-2, not below zero), strict '<' so the highest level wins ties  [ref :566-580]; straight-line code */
 static HD int hv_quant1(int q, int sh, int dsh, int av, int &d) {
+    const HvRd w = hv_rd_make(q);
     const int half = 1 << sh >> 1, dmax = HV_I32MAX - half;
     d = (av > 0x1ffff) ? dmax : hv_min((av & 0x1ffff) << 14, dmax);
     const int lv0 = hv_clip16((d + half) >> sh);
-    const int lo = hv_max(0, lv0 - 2);
     int best = HV_I32MAX, pick = 0;
+#pragma unroll
     for (int t = 0; t < 3; t++) {
-        const int lv = lv0 - t;
-        if (lv >= lo) {
-            const int e = hv_abs(d - (lv << sh)) >> dsh;
-            const int dist = ((e < 46340) ? e * e : HV_I32MAX) >> 7;
-            const int cst = hv_rdcost(q, dist, hv_level_rate(lv));
-            if (cst < best) { best = cst; pick = lv; }
-        }
+        const int lv = hv_max(lv0 - t, 0);
+        const int e = hv_abs(d - (lv << sh)) >> dsh;
+        const int dist = ((e < 46340) ? e * e : HV_I32MAX) >> 7;
+        const int cst = hv_rd(w, dist, hv_level_rate(lv));
+        const bool take = (lv0 - t >= 0) && (cst < best);
+        best = take ? cst : best;
+        pick = take ? lv : pick;
     }
     return pick;
 }
@@ -961,24 +980,156 @@ static HDN void hv_job_chain(int wave, int lane, int q, HvCu cu, int grp, HvGLev
     if (ok && j == 0) L.tsse[t] = total;
     WAVE_SYNC();
 }
+/* 4x4 TU trial with lane = mode: the whole block lives in this lane's registers (no cross-lane traffic).
+   b = raw reference samples (corner, left[8], above[8]); 4x4 blocks never use the smoothed ones  [ref :274-275].
+   Writes levels in scan order to lev_dst[16], the reconstruction (raster) to rec_dst[16]; returns SSE.
+   [ref :1508-1518 = predict / residual / DST / RDOQ / dequant / inverse DST / reconstruct] */
+static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int ty, int tx, int m, HV_LDSP short *lev_dst, HV_LDSP u8 *rec_dst, int &last_out) {
+    const u8 *l = b + 1, *a = b + 9;
+    const int c = b[0];
+    int p[16];
+    if (m == 0) {
+        const int lN = l[4], aN = a[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) p[i * 4 + j] = (4 + (3 - j) * l[i] + (j + 1) * aN + (3 - i) * a[j] + (i + 1) * lN) >> 3;
+    } else if (m == 1) {
+        int dc = 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) dc += l[i] + a[i];
+        dc >>= 3;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                p[i * 4 + j] = (i == 0 && j == 0) ? (2 + 2 * dc + l[0] + a[0]) >> 2 : (i == 0) ? (2 + 3 * dc + a[j]) >> 2 : (j == 0) ? (2 + 3 * dc + l[i]) >> 2 : dc;
+    } else if (m == 10) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) p[i * 4 + j] = (i == 0) ? hv_clip8(l[0] + ((a[j] - c) >> 1)) : l[i];
+    } else if (m == 26) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) p[i * 4 + j] = (j == 0) ? hv_clip8(a[0] + ((l[i] - c) >> 1)) : a[j];
+    } else {
+        /* angular: this mode's reference line r(k), k = -4..9, is laid out once (r(k>0) main side, r(0) corner, r(k<0) the
+           side samples projected through the inverse angle [ref :353-364]); the pixel loop then only indexes it */
+        const bool horiz = m < 18;
+        const int ang = hv_ang[m], inv = hv_invang[m];
+        const u8 *mainr = horiz ? l : a, *sider = horiz ? a : l;
+        u8 *line = line_buf + 4;
+#pragma unroll
+        for (int k = -4; k <= 9; k++) {
+            int v;
+            if (k > 0) v = mainr[k > 8 ? 7 : k - 1];
+            else if (k == 0) v = c;
+            else v = sider[hv_min(hv_max(((128 - inv * k) >> 8) - 1, 0), 7)];   /* entries outside the projected range are never read */
+            line[k] = (u8)v;
+        }
+#pragma unroll
+        for (int st = 0; st < 4; st++) {                         /* st = the index the angle steps along (row for vertical modes) */
+            const int off = ang * (st + 1), oi = off >> 5, of = off & 31;
+#pragma unroll
+            for (int al = 0; al < 4; al++) {
+                const int k1 = oi + al + 1;
+                const int v = ((32 - of) * line[k1] + of * line[k1 + 1] + 16) >> 5;
+                if (horiz) p[al * 4 + st] = v; else p[st * 4 + al] = v;
+            }
+        }
+    }
+    int r[16], t[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[i * 4 + j] = (int)S.org[ty + i][tx + j] - p[i * 4 + j];
+    constexpr int D[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };       /* [ref :391-396] */
+    /* forward: columns (shift 1), rows (shift 8) */
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) t[i * 4 + j] = (D[i * 4] * r[j] + D[i * 4 + 1] * r[4 + j] + D[i * 4 + 2] * r[8 + j] + D[i * 4 + 3] * r[12 + j] + 1) >> 1;
+    const int sh = 19 + q, thr = 9 << sh >> 2, qsh = 5 + q;
+    int lv[16], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int coef = (t[i * 4] * D[j * 4] + t[i * 4 + 1] * D[j * 4 + 1] + t[i * 4 + 2] * D[j * 4 + 2] + t[i * 4 + 3] * D[j * 4 + 3] + 128) >> 8;
+            int d;
+            const int mag = hv_quant1(q, sh, 8, hv_abs(coef), d);
+            lv[i * 4 + j] = coef < 0 ? -mag : mag;
+            sum += hv_min(d, thr);
+        }
+    const int kind = hv_scan_kind(4, m);
+    int last = -1;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (sum < thr) lv[k] = 0;
+        const int si = hv_scan_idx(S, 2, kind, k >> 2, k & 3);
+        if (lv[k] && si > last) last = si;
+        lev_dst[si] = (short)lv[k];
+        r[k] = hv_clip16((int)((unsigned)lv[k] << qsh));
+    }
+    /* inverse: columns with C^T (shift 7), rows (shift 12) */
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) t[i * 4 + j] = hv_clip16((D[i] * r[j] + D[4 + i] * r[4 + j] + D[8 + i] * r[8 + j] + D[12 + i] * r[12 + j] + 64) >> 7);
+    int sse = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int res = hv_clip16((t[i * 4] * D[j] + t[i * 4 + 1] * D[4 + j] + t[i * 4 + 2] * D[8 + j] + t[i * 4 + 3] * D[12 + j] + 2048) >> 12);
+            const int rc = hv_clip8(res + p[i * 4 + j]);
+            const int dd = (int)S.org[ty + i][tx + j] - rc;
+            sse += dd * dd;
+            rec_dst[i * 4 + j] = (u8)rc;
+        }
+    last_out = last;
+    return sse;
+}
+
 /* NxN job (8x8 CU only): per 4x4 sub-block choose the mode with a fresh coder and fresh contexts  [ref :1499-1528] */
 static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
     HvLds &S = HV_S;
     HvLds::Level &L = S.lv[0];
     q = hv_uni(q); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x);
-    const int slot = lane >> 2, j = lane & 3;
     int total = 0;
     HV_PROF2_T0();
     for (int s = 0; s < 4; s++) {
         int l, lb, a, ar;
         hv_sub_avail(s, cu.L, cu.LB, cu.A, cu.AR, l, lb, a, ar);
         const int oy = (s >> 1) * 4, ox = (s & 1) * 4;
-        for (int g = 0; g < 3; g++) {
-            const int mode = g * 16 + slot;
-            const bool ok = mode < HEVCE_NMODES;
-            HvTuOut o = hv_tu_job<4, HvLLev, HvLRec>(wave, lane, q, cu.y + oy, cu.x + ox, cu.y, cu.x, 8, (HvLRec)&S.nxn_crec[0][0], 0, l, lb, a, ar,
-                                     ok ? mode : -1, (HvLLev)S.nxn_lev[ok ? mode : 0], (HvLRec)S.nxn_rec[ok ? mode : 0], 4);
-            if (ok && j == 0) { S.nxn_sse[mode] = o.sse; S.nxn_last[mode] = o.last; S.nxn_sig[mode] = o.cbf; }
+        /* reference samples of this 4x4 (shared by all modes): corner, left + left-below, above + above-right  [ref :1502] */
+        if (lane < 17) {
+            const HV_LDSP u8 *inner = (const HV_LDSP u8 *)&S.nxn_crec[0][0];
+            const int ty = cu.y + oy, tx = cu.x + ox;
+            int corner;
+            if (l && a)  corner = hv_px(S, inner, 0, cu.y, cu.x, 8, ty - 1, tx - 1);
+            else if (l)  corner = hv_px(S, inner, 0, cu.y, cu.x, 8, ty, tx - 1);
+            else if (a)  corner = hv_px(S, inner, 0, cu.y, cu.x, 8, ty - 1, tx);
+            else         corner = 128;
+            int v = corner;
+            if (lane >= 1 && lane <= 8) {
+                const int i = lane - 1;
+                if (i < 4) v = l ? hv_px(S, inner, 0, cu.y, cu.x, 8, ty + i, tx - 1) : corner;
+                else v = lb ? hv_px(S, inner, 0, cu.y, cu.x, 8, ty + i, tx - 1) : (l ? hv_px(S, inner, 0, cu.y, cu.x, 8, ty + 3, tx - 1) : corner);
+            } else if (lane >= 9) {
+                const int i = lane - 9;
+                if (i < 4) v = a ? hv_px(S, inner, 0, cu.y, cu.x, 8, ty - 1, tx + i) : corner;
+                else v = ar ? hv_px(S, inner, 0, cu.y, cu.x, 8, ty - 1, tx + i) : (a ? hv_px(S, inner, 0, cu.y, cu.x, 8, ty - 1, tx + 3) : corner);
+            }
+            S.nxn_bord[lane] = (u8)v;
+        }
+        WAVE_SYNC();
+        if (lane < HEVCE_NMODES) {
+            int last;
+            const int sse = hv_tu4_lane(S, q, S.nxn_bord, S.nxn_line[lane], cu.y + oy, cu.x + ox, lane, (HV_LDSP short *)S.nxn_lev[lane], (HV_LDSP u8 *)S.nxn_rec[lane], last);
+            S.nxn_sse[lane] = sse; S.nxn_last[lane] = last < 0 ? 0 : last; S.nxn_sig[lane] = last >= 0;
         }
         WAVE_SYNC();
         HV_PROF2(S, 0);
@@ -1295,6 +1446,15 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, H
 /* --------------------------------------------------------------------------------------------- */
 static HD void hv_init_tables(HvLds &S, int q, int tid) {
     if (tid < 64) { S.lps4[tid] = hv_lps4[tid]; S.lpsnext[tid] = hv_lpsnext[tid]; }
+    if (tid < 256) {
+        const int lps = (int)((hv_lps4[tid >> 2] >> ((tid & 3) << 3)) & 0xff);
+        S.lpsq[tid] = (u16)(lps | (((lps < 8) ? 6 : hv_clz((unsigned)(lps >> 3)) - 26) << 8));
+    }
+    if (tid >= 256 && tid < 384) {
+        const int cv = tid - 256, st = cv >> 1, mps = cv & 1;
+        S.nxt_mps[cv] = (u8)(st < 62 ? cv + 2 : cv);
+        S.nxt_lps[cv] = (u8)(st == 0 ? (mps ^ 1) : ((hv_lpsnext[st] << 1) | mps));
+    }
     if (tid == 64) {
         /* up-right diagonal order inside a 4x4 group and over 2x2 / 4x4 / 8x8 groups  [ref :1130-1132] */
         int k = 0;

@@ -26,7 +26,6 @@ hevce_test_tu_kernel(const unsigned char *org /*32x32*/, const unsigned char *nb
     HvLds &S = HV_S;
     const int tid = (int)threadIdx.x;
     hv_init_tables(S, q, tid);
-    if (tid < 64) { S.lps4[tid] = hv_lps4[tid]; }
     for (int p = tid; p < 1024; p += 64) S.org[p >> 5][p & 31] = org[p];
     for (int p = tid; p < 33 * 65; p += 64) S.rec[p / 65][HV_RX - 1 + p % 65] = nbr[p];
     if (tid == 0) S.trace = nullptr;
