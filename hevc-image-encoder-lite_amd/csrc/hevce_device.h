@@ -147,7 +147,8 @@ struct alignas(16) HvLds {
     unsigned lps4[64];
     u8  lpsnext[64];
     u16 lpsq[256];                                          /* [state*4 + (range>>6 & 3)] = LPS range | renormalisation shift << 8 */
-    u8  nxt_mps[128], nxt_lps[128];                         /* context byte after an MPS / LPS  [ref HEVCe.c:701-702] */
+    u8  nxt_mps[128], nxt_lps[128];
+    u8  sigtab[35][16];                                     /* sig_coeff_flag context per scan position of a 4x4 group, by (size class, scan, neighbours, first group) */                         /* context byte after an MPS / LPS  [ref HEVCe.c:701-702] */
     u8  d4pos[16], d4idx[16];                               /* diagonal scan inside a 4x4 group: idx->(y<<2|x), (y<<2|x)->idx */
     u8  cgpos[3][64], cgidx[3][64];                         /* group order for 2x2 / 4x4 / 8x8 groups: idx->(gy<<3|gx), gy*ncg+gx->idx */
     u8  ctx_fresh[HEVCE_NCTXP];
@@ -468,24 +469,41 @@ static HD int hv_sigctx(int n, int diag, int y, int x, int nb) {                
     return base + 2;
 }
 
-template <typename P> static HD void hv_tok_remainder(HvTokW<P> &w, int v, int k) {                                                 /* [ref :1154-1169] */
-    if (v < (3 << k)) {
-        const int pre = v >> k;
-        hv_tok_byp(w, (1 << (pre + 1)) - 2, pre + 1);
-        hv_tok_byp(w, v & ((1 << k) - 1), k);
-    } else {
-        int len = k;
-        v -= 3 << k;
-        for (; len < 20 && v >= (1 << len); len++) v -= 1 << len;      /* levels are 16-bit: len <= 15 */
-        const int t = 4 + len - k;
-        hv_tok_byp(w, (1 << t) - 2, t);
-        hv_tok_byp(w, v, len);
-    }
+static HD int hv_sigtab_index(int n, int kind, int nb, int first_cg) {
+    if (n == 4) return kind;
+    if (n == 8) return 3 + kind * 8 + nb * 2 + (first_cg ? 0 : 1);
+    return 27 + nb * 2 + (first_cg ? 0 : 1);
+}
+/* branch-free emission: the token is always stored at the write position and the position advances only when `on`;
+   a slot has headroom for the extra store (<= 110 of 120 token words are ever counted) */
+template <typename P> static HD void hv_emit(HvTokW<P> &w, int tok, int on) { w.p[HV_SLOT_TOK0 + w.n] = (u16)tok; w.n += on; }
+/* bypass bins of length len (<= 24) as <= 3 chunks of <= 8 from the top, exactly like hv_tok_byp  [ref :899-911] */
+template <typename P> static HD void hv_emit_byp(HvTokW<P> &w, int bins, int len, int on) {
+    bins &= (1 << len) - 1;
+    const int n1 = hv_min(len, 8), r1 = len - n1, n2 = hv_min(r1, 8), n3 = r1 - n2;
+    hv_emit(w, HV_TOK_BYP | (n1 << 8) | ((bins >> r1) & ((1 << n1) - 1)), on && n1 > 0);
+    hv_emit(w, HV_TOK_BYP | (n2 << 8) | ((bins >> n3) & ((1 << n2) - 1)), on && n2 > 0);
+    hv_emit(w, HV_TOK_BYP | (n3 << 8) | (bins & ((1 << n3) - 1)), on && n3 > 0);
+}
+/* coeff_abs_level_remaining  [ref :1154-1169] */
+template <typename P> static HD void hv_emit_remainder(HvTokW<P> &w, int v, int k, int on) {
+    /* short form: v < 3<<k: prefix of (v>>k)+1 bins, suffix of k bins.  long form: Exp-Golomb escape */
+    const int shortf = v < (3 << k);
+    const int pre = v >> k;
+    /* escape: the reference subtracts 2^k, 2^(k+1), ... while the rest is >= 2^len; closed form of that loop */
+    const int w2 = hv_max(v - (3 << k), 0) + (1 << k);
+    const int len = 31 - hv_clz((unsigned)w2), u = w2 - (1 << len);
+    const int t = 4 + len - k;
+    const int pbins = shortf ? (1 << (pre + 1)) - 2 : (1 << t) - 2, plen = shortf ? pre + 1 : t;
+    const int sbins = shortf ? (v & ((1 << k) - 1)) : u, slen = shortf ? k : len;
+    hv_emit_byp(w, pbins, plen, on);
+    hv_emit_byp(w, sbins, slen, on);
 }
 
 /* one 4x4 coefficient group of a transform block whose levels lie in SCAN ORDER at lev16[0..15]   [ref :1194-1268]
    cg = the group's index in scan order; last / cgsig describe the whole block (from the TU job).
-   Every loop below has a fixed trip count with predication, so that threads binarising different groups stay converged. */
+   Straight-line code: fixed trip counts, unconditional stores, conditional counts -- threads binarising different groups
+   stay converged and nothing is a branch. */
 template <typename P, typename LP> static HD int hv_tokenize_cg(const HvLds &S, P slot, LP lev16, int n, int lg, int kind, int cg, int last, u64 cgsig) {
     HvTokW<P> w = { slot, 0 };
     const int cg_last = last >> 4;
@@ -498,60 +516,55 @@ template <typename P, typename LP> static HD int hv_tokenize_cg(const HvLds &S, 
         const int right = (gx < ncg - 1) ? (int)((cgsig >> (gy * 8 + gx + 1)) & 1) : 0;
         const int below = (gy < ncg - 1) ? (int)((cgsig >> (gy * 8 + 8 + gx)) & 1) : 0;
         const int nb = (below << 1) | right;
-        if (!first_cg && !at_last_cg) hv_tok_ctx(w, CX_SIGCG + (nb != 0), cgs);
+        hv_emit(w, (CX_SIGCG + (nb != 0)) | (cgs ? 0x80 : 0), !first_cg && !at_last_cg);
         if (cgs || first_cg) {
             const int start = at_last_cg ? (last & 15) : 15;
             int v[16];
+            unsigned nzm = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = cgs ? (int)lev16[k] : 0;
-            /* significance flags, highest scan position first */
-            int nz = 0, signs = 0;
+            for (int k = 0; k < 16; k++) { v[k] = cgs ? (int)lev16[k] : 0; nzm |= (unsigned)(v[k] != 0) << k; }
+            const u8 *tab = S.sigtab[hv_sigtab_index(n, kind, nb, first_cg)];
+            /* significance flags, highest scan position first; position 0 of a later group is inferred when nothing else is set */
+            const int any_above0 = (nzm >> 1) != 0;
 #pragma unroll
             for (int ii = 15; ii >= 0; ii--) {
-                if (ii <= start) {
-                    const int at_last = at_last_cg && ii == start;
-                    if (!at_last && (first_cg || (cgs && (ii != 0 || nz > 0)))) {
-                        int iy, ix;
-                        hv_scan_in(S, kind, ii, iy, ix);
-                        hv_tok_ctx(w, CX_SIG + hv_sigctx(n, kind == 0, gy * 4 + iy, gx * 4 + ix, nb), v[ii] != 0);
-                    }
-                    if (v[ii]) { nz++; signs = (signs << 1) | (v[ii] < 0); }
-                }
+                const int on = (ii <= start) && !(at_last_cg && ii == start) && (ii != 0 || first_cg || any_above0);
+                hv_emit(w, (CX_SIG + tab[ii]) | ((nzm >> ii) & 1 ? 0x80 : 0), on);
             }
-            if (nz > 0) {
-                /* greater1 flags of the first eight, one greater2 flag; the context set remembers the previous group */
-                const int set4 = (first_cg ? 0 : 8), set1 = (first_cg ? 0 : 2);
-                int esc = nz > 8, g2 = -1, c1 = 1, j = 0;
+            const int nz = __builtin_popcount(nzm);
+            /* greater1 flags of the first eight non-zero levels, one greater2 flag; sign bits in the same order */
+            const int set4 = (first_cg ? 0 : 8), set1 = (first_cg ? 0 : 2);
+            int esc = nz > 8, g2 = -1, c1 = 1, j = 0, signs = 0;
 #pragma unroll
-                for (int ii = 15; ii >= 0; ii--) {
-                    if (ii <= start && v[ii] && j < 8) {
-                        const int a = hv_abs(v[ii]);
-                        w.p[HV_SLOT_TOK0 + w.n] = (u16)((CX_ONE + set4 + c1) | (a > 1 ? 0x80 : 0) | HV_TOK_G4); w.n++;
-                        if (a > 1) { c1 = 0; if (g2 < 0) g2 = a > 2; else esc = 1; }
-                        else if (c1 > 0 && c1 < 3) c1++;
-                        j++;
-                    }
-                }
-                if (c1 == 0 && g2 >= 0) { w.p[HV_SLOT_TOK0 + w.n] = (u16)((CX_ABS + set1) | (g2 ? 0x80 : 0) | HV_TOK_G1); w.n++; esc |= g2; }
-                hv_tok_byp(w, signs, nz);
-                if (esc) {
-                    int base = 3, rice = 0;
-                    j = 0;
-#pragma unroll
-                    for (int ii = 15; ii >= 0; ii--) {
-                        if (ii <= start && v[ii]) {
-                            const int a = hv_abs(v[ii]), rem = a - (j < 8 ? base : 1);
-                            if (rem >= 0) {
-                                hv_tok_remainder(w, rem, rice);
-                                if (a > (3 << rice)) rice = hv_min(rice + 1, 4);
-                            }
-                            if (a >= 2) base = 2;
-                            j++;
-                        }
-                    }
-                }
-                hdr = HV_HDR_NZ | (c1 == 0 ? HV_HDR_G1 : 0);
+            for (int ii = 15; ii >= 0; ii--) {
+                const int isnz = (nzm >> ii) & 1;
+                const int a = hv_abs(v[ii]), on = isnz && j < 8, big = a > 1;
+                hv_emit(w, (CX_ONE + set4 + c1) | (big ? 0x80 : 0) | HV_TOK_G4, on);
+                const int first_big = on && big && g2 < 0, more_big = on && big && g2 >= 0;
+                g2 = first_big ? (a > 2) : g2;
+                esc |= more_big;
+                c1 = (on && big) ? 0 : ((on && c1 > 0 && c1 < 3) ? c1 + 1 : c1);
+                signs = isnz ? ((signs << 1) | (v[ii] < 0)) : signs;
+                j += isnz;
             }
+            const int has_g2 = nz > 0 && c1 == 0 && g2 >= 0;
+            hv_emit(w, (CX_ABS + set1) | (g2 > 0 ? 0x80 : 0) | HV_TOK_G1, has_g2);
+            esc |= has_g2 && g2 > 0;
+            hv_emit_byp(w, signs, nz, nz > 0);
+            /* remaining magnitudes with the adaptive Rice parameter */
+            int base = 3, rice = 0;
+            j = 0;
+#pragma unroll
+            for (int ii = 15; ii >= 0; ii--) {
+                const int isnz = (nzm >> ii) & 1;
+                const int a = hv_abs(v[ii]), rem = a - (j < 8 ? base : 1);
+                const int on = isnz && esc && rem >= 0;
+                hv_emit_remainder(w, hv_max(rem, 0), rice, on);
+                rice = (on && a > (3 << rice)) ? hv_min(rice + 1, 4) : rice;
+                base = (isnz && a >= 2) ? 2 : base;
+                j += isnz;
+            }
+            hdr = nz > 0 ? (HV_HDR_NZ | (c1 == 0 ? HV_HDR_G1 : 0)) : 0;
         }
     }
     slot[0] = (u16)(w.n | hdr);
@@ -584,12 +597,11 @@ static HD int hv_link_token(int tok, int g1) {
    exceeds the cost of a candidate that has COMPLETED (or of the split alternative, known beforehand) it cannot be the
    arg-min, which is the LAST candidate of MINIMAL cost (ref :1440 adopts on >=).  Returns 1 when abandoned.
    [ref CABACputBin / CABACputBins :899-933] */
-/* one token through the coder: context-coded bin or bypass chunk, same straight-line code (table driven) */
-static HD void hv_engine_step(const HvLds &S, HvCod &c, u8 *cx, int tok) {
+/* one token through the coder: context-coded bin or bypass chunk, same straight-line code (table driven).
+   cp / cv = the token's context byte address and its (already fetched) value; returns the value written back */
+static HD int hv_engine_step(const HvLds &S, HvCod &c, u8 *cp, int cv, int tok) {
     const int isb = (tok >> 15) & 1;
     const int nb = (tok >> 8) & 15, bv = tok & 0xff;
-    u8 *cp = cx + (isb ? (HEVCE_NCTXP - 1) * HV_TL : (tok & 0x1fff));        /* bypass: pad context, written back unchanged */
-    const int cv = *cp & 0x7f;
     const int e = S.lpsq[((cv & 0x7e) << 1) | ((c.range >> 6) & 3)];
     const int nm = S.nxt_mps[cv], nl = S.nxt_lps[cv];
     const int lps = e & 0xff, shl = e >> 8;
@@ -603,9 +615,13 @@ static HD void hv_engine_step(const HvLds &S, HvCod &c, u8 *cx, int tok) {
     c.low = isb ? low_b : low_c;
     c.range = isb ? c.range : range_c;
     c.nbits -= isb ? nb : sh_c;
-    *cp = (u8)(isb ? cv : (islps ? nl : nm));
+    const int ncv = isb ? cv : (islps ? nl : nm);
+    *cp = (u8)ncv;
     hv_cod_carry_fast(c);
+    return ncv;
 }
+static HD u8 *hv_tok_ctx_ptr(u8 *cx, int tok) { return cx + ((tok & HV_TOK_BYP) ? (HEVCE_NCTXP - 1) * HV_TL : (tok & 0x1fff)); }   /* bypass: pad context */
+
 template <typename ChunkPtr>
 static HD int hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int i0, int i1, int q = 0, int sse = 0, int bits0 = 0, const int *best = nullptr) {
     if (i0 >= i1) return 0;
@@ -614,10 +630,21 @@ static HD int hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int i0, i
     for (; base < i1; base += 8) {
         const HvChunk cur = nxt;
         nxt = sp[(base >> 3) + 1];                                /* requested eight tokens ahead of its first use */
+        /* tokens outside [i0, i1) become no-ops; the context byte of token j+1 is fetched while token j is processed and
+           forwarded when both use the same context */
+        int tok = (base >= i0 && base < i1) ? (int)(cur[0] & 0xffffu) : HV_TOK_NOP;
+        u8 *cp = hv_tok_ctx_ptr(cx, tok);
+        int cv = *cp & 0x7f;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const int i = base + j;
-            if (i >= i0 && i < i1) hv_engine_step(S, c, cx, (int)((cur[j >> 1] >> ((j & 1) << 4)) & 0xffffu));
+            const int in = base + j + 1;
+            int tn = HV_TOK_NOP;
+            if (j < 7) tn = (in >= i0 && in < i1) ? (int)((cur[(j + 1) >> 1] >> (((j + 1) & 1) << 4)) & 0xffffu) : HV_TOK_NOP;
+            u8 *cpn = hv_tok_ctx_ptr(cx, tn);
+            const int cvl = *cpn & 0x7f;
+            const int ncv = hv_engine_step(S, c, cp, cv, tok);
+            cv = (cpn == cp) ? ncv : cvl;
+            cp = cpn; tok = tn;
         }
         if (best && (base & 8) && hv_rdcost(q, sse, hv_cod_bits(c) - bits0) > hv_peek(best)) return 1;
     }
@@ -1325,9 +1352,21 @@ static HD void hv_prepare_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu) 
         const int nslots = hv_trial_slots(n, t);
         HV_GLOBAL u16 *dst = gstream + (size_t)t * HEVCE_STREAM_WORDS;
         const HV_GLOBAL u16 *src = gtok + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0;
-        for (int f = 0; f < nslots; f++) {
-            const int o0 = S.shdr[t][f], off = o0 & 0x7fff, g1 = o0 >> 15, cnt = (S.shdr[t][f + 1] & 0x7fff) - off;
-            for (int k = lane; k < cnt; k += 64) dst[off + k] = (u16)hv_link_token(src[f * HV_SLOT + k], g1);
+        for (int f0 = 0; f0 < nslots; f0 += 4) {                  /* four slots per iteration: their loads are in flight together */
+            int off[4], g1[4], cnt[4], tk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int f = hv_min(f0 + u, nslots - 1);
+                const int o0 = S.shdr[t][f];
+                off[u] = o0 & 0x7fff; g1[u] = o0 >> 15;
+                cnt[u] = (f0 + u < nslots) ? (S.shdr[t][f + 1] & 0x7fff) - off[u] : 0;
+                tk[u] = (lane < cnt[u]) ? (int)src[f * HV_SLOT + lane] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (lane < cnt[u]) dst[off[u] + lane] = (u16)hv_link_token(tk[u], g1[u]);
+                for (int k = lane + 64; k < cnt[u]; k += 64) dst[off[u] + k] = (u16)hv_link_token(src[hv_min(f0 + u, nslots - 1) * HV_SLOT + k], g1[u]);
+            }
         }
     }
     if (tid == 0) {                                              /* slice size of a parent's candidates: done by its last child */
@@ -1477,6 +1516,20 @@ static HD void hv_init_tables(HvLds &S, int q, int tid) {
     if (tid == 300) { S.com.range = 510; S.com.low = 0; S.com.nbits = 23; S.com.nbytes = 0; S.com.bufbyte = 0xff; S.com.zeros = 0; S.com.nout = 0; S.com.pad = 0; }
 }
 
+/* second init step (after the scan tables exist): significance-context tables  [ref :1092-1122 evaluated per position] */
+static HD void hv_init_sigtab(HvLds &S, int tid) {
+    for (int e = tid; e < 35 * 16; e += HV_NTHREADS) {
+        const int tb = e >> 4, ii = e & 15;
+        int n, kind, nb, first;
+        if (tb < 3) { n = 4; kind = tb; nb = 0; first = 1; }
+        else if (tb < 27) { n = 8; kind = (tb - 3) >> 3; nb = ((tb - 3) >> 1) & 3; first = !((tb - 3) & 1); }
+        else { n = 16; kind = 0; nb = ((tb - 27) >> 1) & 3; first = !((tb - 27) & 1); }
+        int iy, ix;
+        hv_scan_in(S, kind, ii, iy, ix);
+        const int gofs = first ? 0 : 4;                       /* any group other than the first: only "(y>>2)|(x>>2) != 0" matters */
+        S.sigtab[tb][ii] = (u8)hv_sigctx(n, kind == 0, gofs + iy, ix, nb);
+    }
+}
 static HD void hv_snapshot(HvLds &S, int lvl, int tid) {
     if (tid == 0) S.ent[lvl] = S.com;
     if (tid < HEVCE_NCTXP) S.ent_ctx[lvl][tid] = S.com_ctx[tid];
@@ -1490,6 +1543,8 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     BLOCK_SYNC();
     HV_TRACE(S, 0, 1);
     hv_init_tables(S, q, tid);
+    BLOCK_SYNC();
+    hv_init_sigtab(S, tid);
     BLOCK_SYNC();
     int ctu = 0;
     for (int y0 = 0; y0 < H; y0 += 32) {

@@ -14,9 +14,11 @@ for n in (4, 8, 16, 32):
         if q == 2: org = (rng.randint(-16, 17, (32, 32)) + 128 + 80).clip(0, 255).astype(np.uint8)
         nbr = rng.randint(0, 256, (33, 65)).astype(np.uint8)
         lev = np.zeros((35, 1024), np.int16); rec = np.zeros((35, 1024), np.uint8); info = np.zeros((35, 4), np.int32)
-        rc = L.hevce_test_tu(org.ctypes.data_as(vp), nbr.ctypes.data_as(vp), n, q, 1, 1, 1, 1, lev.ctypes.data_as(vp), rec.ctypes.data_as(vp), info.ctypes.data_as(vp))
+        lb = 1 if n < 32 else 0      # a 32x32 block at the CTU origin has no left-below rows
+        rc = L.hevce_test_tu(org.ctypes.data_as(vp), nbr.ctypes.data_as(vp), n, q, 1, lb, 1, 1, lev.ctypes.data_as(vp), rec.ctypes.data_as(vp), info.ctypes.data_as(vp))
         assert rc == 0
-        corner = int(nbr[0, 0]); left = np.ascontiguousarray(nbr[1:1 + 2 * n, 0]) if 2 * n <= 32 else np.ascontiguousarray(np.concatenate([nbr[1:33, 0], np.zeros(32, np.uint8)]))
+        corner = int(nbr[0, 0])
+        left = np.ascontiguousarray(nbr[1:1 + 2 * n, 0]) if lb else np.ascontiguousarray(np.concatenate([nbr[1:1 + n, 0], np.full(n, nbr[n, 0], np.uint8)]))
         above = np.ascontiguousarray(nbr[0, 1:1 + 2 * n])
         bad = []
         for m in range(35):
