@@ -129,6 +129,14 @@ def main():
     value = pixels_per_step * args.steps / elapsed / 1e6
     k_avg = float(np.mean(kernel_ms))
     achieved = ALGO_BYTES_PER_PIXEL * H * W / (k_avg * 1e-3) / 1e9
+    # HBM traffic cannot be counted from inside this process: it comes from the committed rocprofv3 --pmc passes of this
+    # kernel (profiles/pmc_traffic.json, bytes per CTU) scaled to this launch's CTU count; null when that file is absent
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = round(json.load(f)["hbm_bytes_per_ctu"] * nctu)
+    except Exception:
+        traffic = None
 
     if rank == 0:
         line = {
@@ -141,7 +149,7 @@ def main():
                                    "kernel + D2H records + host CABAC writer" + ("; RCCL gather of streams to rank 0" if world > 1 else ""),
                        "images_per_gpu": 1, "parallelism": f"image-per-gpu x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 6), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 9), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 9), "traffic": traffic,
                          "kernel": "hevce_analyse_kernel", "kernel_ms_avg": round(k_avg, 3),
                          "us_per_ctu": round(k_avg * 1e3 / nctu, 2),
                          "note": "serial-dependency bound by construction (SURVEY 0.2): one picture = one workgroup chain"},
