@@ -70,6 +70,7 @@ static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v
 #define HV_PROF_T0()  unsigned long long pt_ = __builtin_amdgcn_s_memtime()
 #define HV_PROF2_T0() unsigned long long p2_ = __builtin_amdgcn_s_memtime()
 #define HV_PROF3(S, ph) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof2[ph] += n_ - pt_; pt_ = n_; } } while (0)
+#define HV_PROF3L(k) HV_PROF3(S, 4 + 4 * cu.lvl + (k))
 #define HV_PROF2(S, ph) do { if ((hv_tid() & 63) == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof2[ph] += n_ - p2_; p2_ = n_; } } while (0)
 #define HV_PROF(S, lvl, ph) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof[lvl][ph] += n_ - pt_; pt_ = n_; } } while (0)
 #else
@@ -77,6 +78,7 @@ static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v
 #define HV_PROF2_T0() do { } while (0)
 #define HV_PROF2(S, ph) do { } while (0)
 #define HV_PROF3(S, ph) do { } while (0)
+#define HV_PROF3L(k) do { } while (0)
 #define HV_PROF(S, lvl, ph) do { } while (0)
 #endif
 
@@ -186,7 +188,7 @@ struct alignas(16) HvLds {
     /* control */
     int winner, split_sse;
     unsigned long long prof[3][8];
-    unsigned long long prof2[8];                            /* HEVCE_PROF: inside the NxN job (tu jobs, tokenise, engine, select) */
+    unsigned long long prof2[16];                           /* HEVCE_PROF: inside the NxN job (tu jobs, tokenise, engine, select) */
     int *trace;
     HvWaveScr ws[HV_NWAVES];
 };
@@ -1236,50 +1238,63 @@ static HD void hv_commit_bin(HvLds &S, int ctx, int bin) {
 static HD HV_GLOBAL u8 *hv_level_scratch(const HevceImageDesc &im, int lvl) { return (HV_GLOBAL u8 *)(im.scratch + (size_t)lvl * HEVCE_SCRATCH_LEVEL_BYTES); }
 static HD int hv_trial_slots(int n, int t) { const int tn = t < 35 ? n : (n >> 1); return 1 + (t < 35 ? 1 : 4) * (1 + (tn >> 2) * (tn >> 2)); }
 
-static HD void hv_prepare_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu) {
-    const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, n = cu.n;
+/* a CU is entered: neighbour context  [ref :1369-1373] and empty candidate state.  Needs a barrier before use. */
+static HD void hv_level_begin(HvLds &S, const HvCu cu) {
+    const int tid = hv_tid(), n = cu.n;
+    HvLds::Level &L = S.lv[cu.lvl];
+    const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
+    if (tid == 0) {
+        L.split_inc = (n > S.map_cu[my][mx - 1]) + (n > S.map_cu[my - 1][mx]);
+        L.ml = S.map_pm[my][mx - 1]; L.ma = S.map_pm[my - 1][mx];
+        L.best_cost = HV_I32MAX;
+    }
+    if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = 0; L.tlen[tid] = 0; }
+    if (n == 8) for (int k = tid; k < 8 * 8; k += HV_NTHREADS) (&S.nxn_crec[0][0])[k] = 0;
+}
+
+/* TU-job phase of the 8x8 CU number m (0..3) of the 16x16 CU number k16 (0..3).  Wavefront 0 walks the NxN chain, the
+   longest job by far; the other seven run the 8x8 CU's eight block jobs AND, in the time wavefront 0 leaves them, the
+   jobs of the enclosing CUs, which only depend on samples outside those CUs: all 14 jobs of the 16x16 CU during its first
+   child (m == 0), the 27 jobs of the 32x32 CU during children 1..3 of the first 16x16 CU.  The schedule is static and
+   wave-uniform (SGPRs): no lane-dependent control flow may surround the calls, the jobs use wave-level shuffles. */
+static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m) {
+    const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
+    const int wv = hv_uni(wave);
+    k16 = hv_uni(k16); m = hv_uni(m);
+    HV_GLOBAL u8 *s0 = hv_level_scratch(im, 0), *s1 = hv_level_scratch(im, 1), *s2 = hv_level_scratch(im, 2);
+    if (wv == 0) { hv_job_nxn(wave, lane, q, c8); return; }
+    const int w1 = wv - 1;                                       /* 0..6 */
+    /* 8x8: jobs 0..2 = TU-split chains (16 modes each), 3..7 = single TUs (8 modes each) */
+    if (w1 < 3) hv_job_chain<4>(wave, lane, q, c8, w1, (HvGLev)s0, (HvGRec)(s0 + HV_TL * 1024 * 2));
+    else hv_job_single<8>(wave, lane, q, c8, w1 - 3, (HvGLev)s0, (HvGRec)(s0 + HV_TL * 1024 * 2));
+    if (w1 == 6) hv_job_single<8>(wave, lane, q, c8, 4, (HvGLev)s0, (HvGRec)(s0 + HV_TL * 1024 * 2));
+    if (m == 0) {
+        /* 16x16: 5 chains (8 modes each) on wavefronts 1..5, 9 single TUs (4 modes each) */
+        if (w1 < 5) hv_job_chain<8>(wave, lane, q, c16, w1, (HvGLev)s1, (HvGRec)(s1 + HV_TL * 1024 * 2));
+        else { hv_job_single<16>(wave, lane, q, c16, w1 - 5, (HvGLev)s1, (HvGRec)(s1 + HV_TL * 1024 * 2));
+               hv_job_single<16>(wave, lane, q, c16, w1 - 3, (HvGLev)s1, (HvGRec)(s1 + HV_TL * 1024 * 2)); }
+        if (w1 < 5) hv_job_single<16>(wave, lane, q, c16, 4 + w1, (HvGLev)s1, (HvGRec)(s1 + HV_TL * 1024 * 2));
+    } else if (k16 == 0) {
+        /* 32x32: 9 chains (4 modes each) then 18 single TUs (2 modes each) in pairs: 18 work slots over 3 x 7 */
+        const int idx = (m - 1) * 7 + w1;
+        if (idx < 9) hv_job_chain<16>(wave, lane, q, c32, idx, (HvGLev)s2, (HvGRec)(s2 + HV_TL * 1024 * 2));
+        else if (idx < 18) { hv_job_single<32>(wave, lane, q, c32, 2 * (idx - 9), (HvGLev)s2, (HvGRec)(s2 + HV_TL * 1024 * 2));
+                             hv_job_single<32>(wave, lane, q, c32, 2 * (idx - 9) + 1, (HvGLev)s2, (HvGRec)(s2 + HV_TL * 1024 * 2)); }
+    }
+}
+
+/* candidates of one CU after their TU jobs: engine state from the entry snapshot, binarisation, linking */
+static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu cu, int phases) {
+    const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, n = cu.n;
     HvLds::Level &L = S.lv[cu.lvl];
     HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
     HvGLev glev = (HvGLev)scr;
-    HvGRec grec = (HvGRec)(scr + HV_TL * 1024 * 2);
     HV_GLOBAL u16 *gtok = (HV_GLOBAL u16 *)(scr + HV_TL * 1024 * 3);
     HV_GLOBAL u16 *gstream = gtok + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT;
     const int ntrials = (n == 8) ? 71 : 70;
-    const int njobs = (n == 8) ? 9 : (n == 16) ? 14 : 27;
-
-    /* neighbour context, read at CU entry  [ref :1369-1373] */
     const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
-    const int split_inc = (n > S.map_cu[my][mx - 1]) + (n > S.map_cu[my - 1][mx]);
-    const int ml = S.map_pm[my][mx - 1], ma = S.map_pm[my - 1][mx];
-    if (tid == 0) { L.split_inc = split_inc; L.ml = ml; L.ma = ma; L.best_cost = HV_I32MAX; }
-    if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = 0; L.tlen[tid] = 0; }
-    for (int k = tid; k < 8 * 8; k += HV_NTHREADS) (&S.nxn_crec[0][0])[k] = 0;
-    BLOCK_SYNC();
+    const int split_inc = L.split_inc, ml = L.ml, ma = L.ma;
     HV_PROF_T0();
-
-    /* ---------------- TU jobs: static round-robin over the wavefronts, longest jobs first ----------------
-       Everything controlling this loop is wave-uniform and lives in SGPRs: no lane-dependent control flow may surround
-       the calls, the jobs use wave-level shuffles. */
-    {
-        const int wv = hv_uni(wave), nj = hv_uni(njobs), nn = hv_uni(n);
-        for (int round = 0; round * HV_NWAVES < nj; round++) {
-            const int job = round * HV_NWAVES + ((round & 1) ? HV_NWAVES - 1 - wv : wv);
-            if (job >= nj) continue;
-            if (nn == 8) {
-                if (job == 0) hv_job_nxn(wave, lane, q, cu);
-                else if (job < 4) hv_job_chain<4>(wave, lane, q, cu, job - 1, glev, grec);
-                else hv_job_single<8>(wave, lane, q, cu, job - 4, glev, grec);
-            } else if (nn == 16) {
-                if (job < 5) hv_job_chain<8>(wave, lane, q, cu, job, glev, grec);
-                else hv_job_single<16>(wave, lane, q, cu, job - 5, glev, grec);
-            } else {
-                if (job < 9) hv_job_chain<16>(wave, lane, q, cu, job, glev, grec);
-                else hv_job_single<32>(wave, lane, q, cu, job - 9, glev, grec);
-            }
-        }
-    }
-    BLOCK_SYNC();                                               /* the NxN job borrows the 8x8 level's context columns */
-    HV_PROF(S, cu.lvl, 0);
     /* candidates start from the CU's entry snapshot  [ref :1423-1424] */
     for (int k = tid; k < HEVCE_NCTXP * HV_TL; k += HV_NTHREADS) L.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[cu.lvl][k / HV_TL];
     if (tid < ntrials) L.tregs[tid] = S.ent[cu.lvl];
@@ -1303,7 +1318,7 @@ static HD void hv_prepare_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu) 
             if (kind == 2) sh = (u16)hv_tokenize_cg(S, slot, (const HV_LDSP short *)&S.nxn_bestlev[tu][0], tn, tlg, hv_scan_kind(tn, md), cg, L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig);
             else sh = (u16)hv_tokenize_cg(S, slot, (const HV_GLOBAL short *)(glev + t * 1024 + tu * tn * tn + cg * 16), tn, tlg, hv_scan_kind(tn, md), cg, L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig);
         }
-        if (n == 8) HV_PROF3(S, 4);
+        HV_PROF3L(0);
         for (int item = tid; item < ntrials * 4; item += HV_NTHREADS) {               /* transform-block header slots */
             const int t = item >> 2, tu = item & 3;
             const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
@@ -1330,7 +1345,7 @@ static HD void hv_prepare_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu) 
         }
     }
     BLOCK_SYNC();
-    if (n == 8) HV_PROF3(S, 5);
+    HV_PROF3L(1);
     /* ---------------- link: slot offsets and greater1-set memory per candidate, then one contiguous stream each -------- */
     for (int t = tid; t < ntrials; t += HV_NTHREADS) {
         const int nslots = hv_trial_slots(n, t);
@@ -1346,7 +1361,7 @@ static HD void hv_prepare_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu) 
         L.tlen[t] = off;
     }
     BLOCK_SYNC();
-    if (n == 8) HV_PROF3(S, 6);
+    HV_PROF3L(2);
     /* copy: one wavefront per candidate walks its slots; lane k moves token k of the slot (coalesced 2-byte stores) */
     for (int t = hv_uni(wave); t < ntrials; t += HV_NWAVES) {
         const int nslots = hv_trial_slots(n, t);
@@ -1372,11 +1387,10 @@ static HD void hv_prepare_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu) 
     if (tid == 0) {                                              /* slice size of a parent's candidates: done by its last child */
         int mx_len = 0;
         for (int t = 0; t < ntrials; t++) mx_len = hv_max(mx_len, L.tlen[t]);
-        const int phases = (n == 8) ? 1 : (n == 16 ? 4 : 16);
         L.quota = (n == 8) ? 0x7fffffff : ((mx_len + phases - 1) / phases + 16);
     }
     BLOCK_SYNC();
-    if (n == 8) HV_PROF3(S, 7);
+    HV_PROF3L(3);
     HV_PROF(S, cu.lvl, 5);
 }
 
@@ -1539,7 +1553,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int tid = hv_tid(), q = im.qpd6, H = im.H, W = im.W;
     if (tid == 0) S.trace = im.trace;
     if (tid < 24) (&S.prof[0][0])[tid] = 0;
-    if (tid < 8) S.prof2[tid] = 0;
+    if (tid < 16) S.prof2[tid] = 0;
     BLOCK_SYNC();
     HV_TRACE(S, 0, 1);
     hv_init_tables(S, q, tid);
@@ -1593,23 +1607,30 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                 }
                 if (step == 0) {                                 /* entering the 32x32 CU */
                     hv_snapshot(S, 2, tid);
+                    hv_level_begin(S, c32);
                     BLOCK_SYNC();
-                    hv_prepare_cu(S, im, c32);
                     if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + S.lv[2].split_inc, 1);
                     BLOCK_SYNC();
                 }
                 if (step < 20 && m == 0) {                       /* entering a 16x16 CU */
                     hv_snapshot(S, 1, tid);
+                    hv_level_begin(S, c16);
                     BLOCK_SYNC();
-                    hv_prepare_cu(S, im, c16);
                     if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + S.lv[1].split_inc, 1);
                     BLOCK_SYNC();
                 }
                 if (cu.n == 8) {
                     hv_snapshot(S, 0, tid);
+                    hv_level_begin(S, cu);
                     BLOCK_SYNC();
-                    hv_prepare_cu(S, im, cu);
-                    hv_engine_phase(S, im, 7, 0);
+                    HV_PROF_T0();
+                    hv_jobs_phase(S, im, cu, c16, c32, k, m);
+                    BLOCK_SYNC();                                /* the NxN job borrows the 8x8 level's context columns */
+                    HV_PROF(S, 0, 0);
+                    hv_prepare_streams(S, im, cu, 1);
+                    if (m == 0) hv_prepare_streams(S, im, c16, 4);
+                    if (k == 0 && m == 3) hv_prepare_streams(S, im, c32, 13);     /* its jobs ran during m = 1..3 */
+                    hv_engine_phase(S, im, (k == 0 && m < 3) ? 3 : 7, 0);
                 }
                 hv_decide_cu(S, im, cu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr);
             }
@@ -1635,6 +1656,6 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     }
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     if (im.trace && tid < 24) { ((unsigned long long *)im.trace)[tid] = (&S.prof[0][0])[tid]; }
-    if (im.trace && tid < 8) { ((unsigned long long *)im.trace)[24 + tid] = S.prof2[tid]; }
+    if (im.trace && tid < 16) { ((unsigned long long *)im.trace)[24 + tid] = S.prof2[tid]; }
 #endif
 }

@@ -18,8 +18,10 @@ nctu = (hevce.pad32(h) // 32) * (hevce.pad32(w) // 32)
 tot = prof.sum()
 print(f"{w}x{h}: kernel {tm['kernel_ms']:.1f} ms, {tm['kernel_ms']*1e3/nctu:.0f} us/CTU, stamped cycles {tot/1e6:.1f} M ({tot/nctu/1e3:.0f} k/CTU)")
 names = ["TU jobs", "ctx init", "engine", "arg-min", "commit", "binarise"]
-p2 = tr[48:64].view(np.uint64)
-print("  8x8 binarise/link:", "  ".join(f"{nm} {100.0*p2[4+i]/tot:5.1f}%" for i, nm in enumerate(("ctx+groups", "headers", "offsets", "copy"))), f"  engine phases {100.0*prof[0,6]/tot:5.1f}%")
+p2 = tr[48:80].view(np.uint64)
+for lvl, nm in enumerate(("8x8", "16x16", "32x32")):
+    print(f"  {nm} binarise/link:", "  ".join(f"{k} {100.0*p2[4+4*lvl+i]/tot:5.1f}%" for i, k in enumerate(("ctx+groups", "headers", "offsets", "copy"))))
+print(f"  engine phases {100.0*prof[0,6]/tot:5.1f}%")
 print("  NxN job:", "  ".join(f"{nm} {100.0*p2[i]/tot:5.1f}%" for i, nm in enumerate(("tu jobs", "tokenise", "engine", "select"))))
 for lvl, nm in enumerate(("8x8", "16x16", "32x32")):
     print(f"  CU {nm:6s}", "  ".join(f"{names[p]} {100.0*prof[lvl,p]/tot:5.1f}%" for p in range(6)))
