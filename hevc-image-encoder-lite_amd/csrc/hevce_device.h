@@ -369,6 +369,7 @@ static HD void hv_terminate(HvCod &c, int bin) {                                
 #define HV_HDR_G1      0x200
 #define HV_HDR_RESET   0x400
 
+typedef unsigned HvChunk __attribute__((vector_size(16)));   /* eight 16-bit tokens, loaded as one dwordx4 */
 template <typename P> struct HvTokW { P p; int n; };
 #define HV_SLOT_TOK0 8                      /* tokens start 16 bytes into the slot so that chunks of 8 load as one dwordx4 */
 template <typename P> static HD void hv_tok_ctx(HvTokW<P> &w, int ctx, int bin) { w.p[HV_SLOT_TOK0 + w.n] = (u16)(ctx | (bin ? 0x80 : 0)); w.n++; }
@@ -393,68 +394,112 @@ static HD void hv_mpm(int left, int above, int out[3]) {                        
 
 struct HvModes { int mode[4], left[4], above[4]; };
 
-/* CU header slot: split_cu_flag=0, part_mode, luma modes (all prev_intra_luma_pred_flags first, then mpm_idx /
-   rem_intra_luma_pred_mode), chroma mode, split_transform_flag, cbf_cb, cbf_cr   [ref :943-1033, 1282-1287] */
-template <typename P> static HD int hv_tokenize_cu(P slot, int n, int lg, int kind, int split_inc, const HvModes &pm) {
-    HvTokW<P> w = { slot, 0 };
-    if (n >= 16) hv_tok_ctx(w, CX_SPLIT_CU + split_inc, 0);
-    if (n == 8) hv_tok_ctx(w, CX_PART, kind != 2);
-    const int parts = kind == 2 ? 4 : 1;
-    int hit[4], rem[4];
-    for (int i = 0; i < 4; i++) {
-        if (i < parts) {
-            int p[3];
-            hv_mpm(pm.left[i], pm.above[i], p);
-            int h = -1;
-            for (int j = 0; j < 3; j++) if (p[j] == pm.mode[i]) h = j;
-            int a = p[0], b = p[1], d = p[2], t;                   /* descending sort, then skip the candidates */
-            if (a < b) { t = a; a = b; b = t; }
-            if (b < d) { t = b; b = d; d = t; }
-            if (a < b) { t = a; a = b; b = t; }
-            int r = pm.mode[i];
-            if (r > a) r--;
-            if (r > b) r--;
-            if (r > d) r--;
-            hit[i] = h; rem[i] = r;
-            hv_tok_ctx(w, CX_YPM, h >= 0);
-        }
-    }
-    for (int i = 0; i < 4; i++) {
-        if (i < parts) {
-            if (hit[i] >= 0) { hv_tok_byp(w, hit[i] > 0, 1); if (hit[i] > 0) hv_tok_byp(w, hit[i] - 1, 1); }
-            else hv_tok_byp(w, rem[i], 5);
-        }
-    }
-    hv_tok_ctx(w, CX_UVPM, 0);
-    if (kind != 2) hv_tok_ctx(w, CX_SPLIT_TU + (5 - lg), kind == 1);
-    hv_tok_ctx(w, CX_UVCBF, 0);
-    hv_tok_ctx(w, CX_UVCBF, 0);
-    slot[0] = (u16)w.n;
-    return w.n;
+/* Token writers.  hv_emit() is branch-free: the token is always stored at the write position and the position advances
+   only when `on`; a slot has headroom for the extra store (<= 110 of 120 token words are ever counted).
+   HvTokW<P>: direct stores (slots in LDS: the NxN sub-search). */
+template <typename P> static HD void hv_emit(HvTokW<P> &w, int tok, int on) { w.p[HV_SLOT_TOK0 + w.n] = (u16)tok; w.n += on; }
+template <typename P> static HD void hv_tok_checkpoint(HvTokW<P> &) { }
+template <typename P> static HD int  hv_tok_finish(HvTokW<P> &w, int hdr) { w.p[0] = (u16)(w.n | hdr); return w.n | hdr; }
+
+/* Writer for slots in HBM.  Sixty-four lanes storing single 16-bit tokens into sixty-four different slots cost one
+   memory transaction per lane and token (measured: 60 % of the binarisation time).  Tokens therefore go to a small ring
+   in the wavefront's LDS scratch (32 tokens per lane, lane-transposed: dword row r of lane l at r*64+l, conflict free)
+   and leave it as 16-byte chunks.  hv_tok_checkpoint() writes out up to three complete chunks; between two checkpoints
+   at most 24 tokens may be added. */
+typedef unsigned __attribute__((may_alias)) HvRingWord;    /* written as 16-bit halves, read back as dwords */
+struct HvTokRing { HV_LDSP HvRingWord *ring; HV_GLOBAL u16 *slot; int n, fl; };
+static HD HvTokRing hv_tok_ring(HvLds &S, HV_GLOBAL u16 *slot) {
+    const int tid = hv_tid();
+    HvTokRing w = { (HV_LDSP HvRingWord *)&S.ws[tid >> 6] + (tid & 63), slot, 0, 0 };
+    return w;
+}
+static HD void hv_emit(HvTokRing &w, int tok, int on) {
+    ((HV_LDSP u16 *)(w.ring + ((w.n >> 1) & 15) * 64))[w.n & 1] = (u16)tok;
+    w.n += on;
+}
+static HD void hv_tok_flush_chunk(HvTokRing &w) {
+    const HV_LDSP HvRingWord *r = w.ring + ((w.fl >> 1) & 15) * 64;
+    HvChunk c;
+    c[0] = r[0]; c[1] = r[64]; c[2] = r[128]; c[3] = r[192];
+    *(HV_GLOBAL HvChunk *)(w.slot + HV_SLOT_TOK0 + w.fl) = c;
+    w.fl += 8;
+}
+static HD void hv_tok_checkpoint(HvTokRing &w) {
+    if (w.n - w.fl >= 8) hv_tok_flush_chunk(w);
+    if (w.n - w.fl >= 8) hv_tok_flush_chunk(w);
+    if (w.n - w.fl >= 8) hv_tok_flush_chunk(w);
+}
+static HD int hv_tok_finish(HvTokRing &w, int hdr) {          /* after a checkpoint: fewer than 8 tokens are pending */
+    hv_tok_flush_chunk(w);
+    return w.n | hdr;
 }
 
-/* TU header slot: cbf_luma (unless the caller is the NxN sub-search, which codes bare residuals) and the position of
-   the last significant coefficient   [ref :1038-1087, 1192] */
-template <typename P> static HD int hv_tokenize_tu(const HvLds &S, P slot, int n, int lg, int kind_scan, int with_cbf, int cbf_ctx, int cbf, int last) {
-    HvTokW<P> w = { slot, 0 };
-    if (with_cbf) hv_tok_ctx(w, cbf_ctx, cbf);
-    if (cbf || !with_cbf) {
-        int gy, gx, iy, ix;
-        hv_scan_cg(S, lg, kind_scan, last >> 4, gy, gx);
-        hv_scan_in(S, kind_scan, last & 15, iy, ix);
-        const int y = gy * 4 + iy, x = gx * 4 + ix;
-        const int cls = lg - 2, sh = (n == 4) ? 0 : 1;
-        int ty = kind_scan == 2 ? x : y, tx = kind_scan == 2 ? y : x;
-        const int ggy = hv_lastgrp[ty], ggx = hv_lastgrp[tx], gmax = hv_lastgrp[n - 1];
-        for (int i = 0; i < ggx; i++) hv_tok_ctx(w, CX_LASTX + 5 * cls + (i >> sh), 1);
-        if (ggx < gmax)               hv_tok_ctx(w, CX_LASTX + 5 * cls + (ggx >> sh), 0);
-        for (int i = 0; i < ggy; i++) hv_tok_ctx(w, CX_LASTY + 5 * cls + (i >> sh), 1);
-        if (ggy < gmax)               hv_tok_ctx(w, CX_LASTY + 5 * cls + (ggy >> sh), 0);
-        if (ggx > 3) { tx -= hv_lastmin[ggx]; for (int i = ((ggx - 2) >> 1) - 1; i >= 0; i--) hv_tok_byp(w, (tx >> i) & 1, 1); }
-        if (ggy > 3) { ty -= hv_lastmin[ggy]; for (int i = ((ggy - 2) >> 1) - 1; i >= 0; i--) hv_tok_byp(w, (ty >> i) & 1, 1); }
+/* CU header slot: split_cu_flag=0, part_mode, luma modes (all prev_intra_luma_pred_flags first, then mpm_idx /
+   rem_intra_luma_pred_mode), chroma mode, split_transform_flag, cbf_cb, cbf_cr   [ref :943-1033, 1282-1287]
+   Straight-line: every possible token is stored, the write position advances only for the ones that exist. */
+template <typename WR> static HD int hv_tokenize_cu(WR &w, int n, int lg, int kind, int split_inc, const HvModes &pm) {
+    hv_emit(w, CX_SPLIT_CU + split_inc, n >= 16);
+    hv_emit(w, CX_PART | (kind != 2 ? 0x80 : 0), n == 8);
+    const int parts = kind == 2 ? 4 : 1;
+    int hit[4], rem[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int p[3];
+        hv_mpm(pm.left[i], pm.above[i], p);
+        const int md = pm.mode[i];
+        const int h = (p[2] == md) ? 2 : (p[1] == md) ? 1 : (p[0] == md) ? 0 : -1;
+        const int hi = hv_max(p[0], hv_max(p[1], p[2])), lo = hv_min(p[0], hv_min(p[1], p[2])), mid = p[0] + p[1] + p[2] - hi - lo;
+        int r = md;                                            /* skip the candidates from the largest down */
+        r -= (r > hi); r -= (r > mid); r -= (r > lo);
+        hit[i] = h; rem[i] = r;
+        hv_emit(w, CX_YPM | (h >= 0 ? 0x80 : 0), i < parts);
     }
-    slot[0] = (u16)(w.n | HV_HDR_RESET);
-    return w.n | HV_HDR_RESET;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int on = i < parts, ishit = hit[i] >= 0;
+        hv_emit(w, HV_TOK_BYP | (1 << 8) | (hit[i] > 0), on && ishit);
+        hv_emit(w, HV_TOK_BYP | (1 << 8) | ((hit[i] - 1) & 1), on && hit[i] > 0);
+        hv_emit(w, HV_TOK_BYP | (5 << 8) | (rem[i] & 31), on && !ishit);
+    }
+    hv_emit(w, CX_UVPM, 1);
+    hv_emit(w, (CX_SPLIT_TU + (5 - lg)) | (kind == 1 ? 0x80 : 0), kind != 2);
+    hv_emit(w, CX_UVCBF, 1);
+    hv_emit(w, CX_UVCBF, 1);
+    hv_tok_checkpoint(w);
+    return hv_tok_finish(w, 0);
+}
+
+/* last_sig_coeff prefix group of a coordinate and the smallest coordinate of a group, in closed form
+   (tables HEVCE_TAB_LASTGRP / HEVCE_TAB_LASTMIN; a per-lane table read would be a memory access)  [ref :1038-1045] */
+static HD int hv_last_group(int v) { const int l2 = 31 - hv_clz((unsigned)hv_max(v, 1)); return v < 4 ? v : 2 * l2 + ((v >> (l2 - 1)) & 1); }
+static HD int hv_last_min(int g) { return g < 4 ? g : (2 + (g & 1)) << ((g >> 1) - 1); }
+
+/* TU header slot: cbf_luma (unless the caller is the NxN sub-search, which codes bare residuals) and the position of
+   the last significant coefficient   [ref :1038-1087, 1192].  Straight-line like the CU header (<= 25 tokens). */
+template <typename WR> static HD int hv_tokenize_tu(const HvLds &S, WR &w, int n, int lg, int kind_scan, int with_cbf, int cbf_ctx, int cbf, int last) {
+    hv_emit(w, cbf_ctx | (cbf ? 0x80 : 0), with_cbf);
+    const int on0 = cbf || !with_cbf;
+    int gy, gx, iy, ix;
+    hv_scan_cg(S, lg, kind_scan, last >> 4, gy, gx);
+    hv_scan_in(S, kind_scan, last & 15, iy, ix);
+    const int y = gy * 4 + iy, x = gx * 4 + ix;
+    const int cls = lg - 2, sh = (n == 4) ? 0 : 1;
+    int ty = kind_scan == 2 ? x : y, tx = kind_scan == 2 ? y : x;
+    const int ggy = hv_last_group(ty), ggx = hv_last_group(tx), gmax = 2 * lg - 1;       /* gmax = group of n - 1 */
+#pragma unroll
+    for (int i = 0; i < 9; i++) hv_emit(w, (CX_LASTX + 5 * cls + (i >> sh)) | 0x80, on0 && i < ggx);
+    hv_emit(w, CX_LASTX + 5 * cls + (ggx >> sh), on0 && ggx < gmax);
+#pragma unroll
+    for (int i = 0; i < 9; i++) hv_emit(w, (CX_LASTY + 5 * cls + (i >> sh)) | 0x80, on0 && i < ggy);
+    hv_emit(w, CX_LASTY + 5 * cls + (ggy >> sh), on0 && ggy < gmax);
+    const int nx = ggx > 3 ? ((ggx - 2) >> 1) : 0, ny = ggy > 3 ? ((ggy - 2) >> 1) : 0;   /* suffix bits, one chunk per bit */
+    tx -= hv_last_min(ggx); ty -= hv_last_min(ggy);
+#pragma unroll
+    for (int i = 2; i >= 0; i--) hv_emit(w, HV_TOK_BYP | (1 << 8) | ((tx >> i) & 1), on0 && i < nx);
+#pragma unroll
+    for (int i = 2; i >= 0; i--) hv_emit(w, HV_TOK_BYP | (1 << 8) | ((ty >> i) & 1), on0 && i < ny);
+    hv_tok_checkpoint(w);
+    return hv_tok_finish(w, HV_HDR_RESET);
 }
 
 static HD int hv_sigctx(int n, int diag, int y, int x, int nb) {                                           /* [ref :1092-1122] */
@@ -476,11 +521,8 @@ static HD int hv_sigtab_index(int n, int kind, int nb, int first_cg) {
     if (n == 8) return 3 + kind * 8 + nb * 2 + (first_cg ? 0 : 1);
     return 27 + nb * 2 + (first_cg ? 0 : 1);
 }
-/* branch-free emission: the token is always stored at the write position and the position advances only when `on`;
-   a slot has headroom for the extra store (<= 110 of 120 token words are ever counted) */
-template <typename P> static HD void hv_emit(HvTokW<P> &w, int tok, int on) { w.p[HV_SLOT_TOK0 + w.n] = (u16)tok; w.n += on; }
 /* bypass bins of length len (<= 24) as <= 3 chunks of <= 8 from the top, exactly like hv_tok_byp  [ref :899-911] */
-template <typename P> static HD void hv_emit_byp(HvTokW<P> &w, int bins, int len, int on) {
+template <typename WR> static HD void hv_emit_byp(WR &w, int bins, int len, int on) {
     bins &= (1 << len) - 1;
     const int n1 = hv_min(len, 8), r1 = len - n1, n2 = hv_min(r1, 8), n3 = r1 - n2;
     hv_emit(w, HV_TOK_BYP | (n1 << 8) | ((bins >> r1) & ((1 << n1) - 1)), on && n1 > 0);
@@ -488,7 +530,7 @@ template <typename P> static HD void hv_emit_byp(HvTokW<P> &w, int bins, int len
     hv_emit(w, HV_TOK_BYP | (n3 << 8) | (bins & ((1 << n3) - 1)), on && n3 > 0);
 }
 /* coeff_abs_level_remaining  [ref :1154-1169] */
-template <typename P> static HD void hv_emit_remainder(HvTokW<P> &w, int v, int k, int on) {
+template <typename WR> static HD void hv_emit_remainder(WR &w, int v, int k, int on) {
     /* short form: v < 3<<k: prefix of (v>>k)+1 bins, suffix of k bins.  long form: Exp-Golomb escape */
     const int shortf = v < (3 << k);
     const int pre = v >> k;
@@ -506,8 +548,7 @@ template <typename P> static HD void hv_emit_remainder(HvTokW<P> &w, int v, int 
    cg = the group's index in scan order; last / cgsig describe the whole block (from the TU job).
    Straight-line code: fixed trip counts, unconditional stores, conditional counts -- threads binarising different groups
    stay converged and nothing is a branch. */
-template <typename P, typename LP> static HD int hv_tokenize_cg(const HvLds &S, P slot, LP lev16, int n, int lg, int kind, int cg, int last, u64 cgsig) {
-    HvTokW<P> w = { slot, 0 };
+template <typename WR, typename LP> static HD int hv_tokenize_cg(const HvLds &S, WR &w, LP lev16, int n, int lg, int kind, int cg, int last, u64 cgsig) {
     const int cg_last = last >> 4;
     int hdr = 0;
     if (cg <= cg_last) {
@@ -533,6 +574,7 @@ template <typename P, typename LP> static HD int hv_tokenize_cg(const HvLds &S, 
                 const int on = (ii <= start) && !(at_last_cg && ii == start) && (ii != 0 || first_cg || any_above0);
                 hv_emit(w, (CX_SIG + tab[ii]) | ((nzm >> ii) & 1 ? 0x80 : 0), on);
             }
+            hv_tok_checkpoint(w);                                  /* <= 17 tokens so far */
             const int nz = __builtin_popcount(nzm);
             /* greater1 flags of the first eight non-zero levels, one greater2 flag; sign bits in the same order */
             const int set4 = (first_cg ? 0 : 8), set1 = (first_cg ? 0 : 2);
@@ -565,12 +607,13 @@ template <typename P, typename LP> static HD int hv_tokenize_cg(const HvLds &S, 
                 rice = (on && a > (3 << rice)) ? hv_min(rice + 1, 4) : rice;
                 base = (isnz && a >= 2) ? 2 : base;
                 j += isnz;
+                if ((ii & 3) == 2) hv_tok_checkpoint(w);          /* <= 11 + 2 x 5, then <= 4 x 5 tokens per section */
             }
             hdr = nz > 0 ? (HV_HDR_NZ | (c1 == 0 ? HV_HDR_G1 : 0)) : 0;
         }
     }
-    slot[0] = (u16)(w.n | hdr);
-    return w.n | hdr;
+    hv_tok_checkpoint(w);
+    return hv_tok_finish(w, hdr);
 }
 
 /* Final token format in a LINKED stream (one contiguous stream per candidate, see hv_link_*):
@@ -579,7 +622,6 @@ template <typename P, typename LP> static HD int hv_tokenize_cg(const HvLds &S, 
      bypass chunk: bit15=1, bits8-11 length, bits0-7 bins (length 0 = no-op padding)                              */
 #define HV_CX(i) (cx + (i) * HV_TL)
 #define HV_TOK_NOP HV_TOK_BYP
-typedef unsigned HvChunk __attribute__((vector_size(16)));   /* eight 16-bit tokens, loaded as one dwordx4 */
 static HD int hv_chunk_get(const HvChunk &c, int i) {
     const unsigned lo = (i & 4) ? c[2] : c[0], hi = (i & 4) ? c[3] : c[1];
     const unsigned d = (i & 2) ? hi : lo;
@@ -1177,8 +1219,10 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
             HV_LDSP u16 *tk = (HV_LDSP u16 *)S.nxn_tok[lane];
             const int ks = hv_scan_kind(4, lane);
             /* the two slots are laid out so that their tokens are contiguous from tk[8]; one group: no set memory */
-            const int na = hv_tokenize_tu(S, tk, 4, 2, ks, 0, 0, 1, S.nxn_last[lane]) & 0xff;
-            const int nb = hv_tokenize_cg(S, tk + na, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0)) & 0xff;
+            HvTokW<HV_LDSP u16 *> wa = { tk, 0 };
+            const int na = hv_tokenize_tu(S, wa, 4, 2, ks, 0, 0, 1, S.nxn_last[lane]) & 0xff;
+            HvTokW<HV_LDSP u16 *> wb = { tk + na, 0 };
+            const int nb = hv_tokenize_cg(S, wb, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0)) & 0xff;
             for (int k = 0; k < na + nb; k++) tk[HV_SLOT_TOK0 + k] = (u16)hv_link_token(tk[HV_SLOT_TOK0 + k], 0);
             HV_PROF2(S, 1);
             hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), 0, na + nb);
@@ -1283,6 +1327,51 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     }
 }
 
+/* binarisation work items of hv_prepare_streams (slot numbering: see there) */
+static HD void hv_bin_group(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, HvGLev glev, int t, int gi) {
+    const int kind = t < 35 ? 0 : 1;                             /* one block of the CU size / four of half the size */
+    const int tn = kind == 0 ? cu.n : (cu.n >> 1), tlg = kind == 0 ? cu.lg : cu.lg - 1, ncgt = (tn >> 2) * (tn >> 2);
+    const int tu = gi / ncgt, r = gi % ncgt, cg = ncgt - 1 - r;
+    u16 &sh = S.shdr[t][1 + tu * (1 + ncgt) + 1 + r];
+    if (!L.tinfo[t][tu].cbf) { sh = 0; return; }
+    HvTokRing w = hv_tok_ring(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt) + 1 + r) * HV_SLOT);
+    sh = (u16)hv_tokenize_cg(S, w, (const HV_GLOBAL short *)(glev + t * 1024 + tu * tn * tn + cg * 16), tn, tlg,
+                             hv_scan_kind(tn, kind == 0 ? t : t - 35), cg, L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig);
+}
+static HD void hv_bin_group_nxn(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, int tu) {   /* candidate 70: levels in LDS */
+    const int t = 70;
+    u16 &sh = S.shdr[t][1 + tu * 2 + 1];
+    if (!L.tinfo[t][tu].cbf) { sh = 0; return; }
+    HvTokRing w = hv_tok_ring(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * 2 + 1) * HV_SLOT);
+    sh = (u16)hv_tokenize_cg(S, w, (const HV_LDSP short *)&S.nxn_bestlev[tu][0], 4, 2, hv_scan_kind(4, S.nxn_modes[tu]), 0,
+                             L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig);
+}
+static HD void hv_bin_tu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, int t, int tu) {
+    const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
+    const int tn = kind == 0 ? cu.n : (cu.n >> 1), tlg = kind == 0 ? cu.lg : cu.lg - 1, ncgt = (tn >> 2) * (tn >> 2);
+    const int md = kind == 0 ? t : kind == 1 ? t - 35 : S.nxn_modes[tu];
+    HvTokRing w = hv_tok_ring(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt)) * HV_SLOT);
+    S.shdr[t][1 + tu * (1 + ncgt)] = (u16)hv_tokenize_tu(S, w, tn, tlg, hv_scan_kind(tn, md), 1, kind == 0 ? CX_YCBF + 1 : CX_YCBF,
+                                                         L.tinfo[t][tu].cbf, L.tinfo[t][tu].last);
+}
+static HD void hv_bin_cu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, int t) {
+    const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
+    const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
+    HvModes pm;
+    for (int s4 = 0; s4 < 4; s4++) { pm.mode[s4] = 0; pm.left[s4] = 0; pm.above[s4] = 0; }
+    pm.left[0] = L.ml; pm.above[0] = L.ma;
+    if (kind == 0) pm.mode[0] = t;
+    else if (kind == 1) pm.mode[0] = t - 35;
+    else {
+        for (int s4 = 0; s4 < 4; s4++) pm.mode[s4] = S.nxn_modes[s4];
+        pm.left[1] = pm.mode[0];  pm.above[1] = S.map_pm[my - 1][mx + 1];                 /* [ref :1531-1538] */
+        pm.left[2] = S.map_pm[my + 1][mx - 1];  pm.above[2] = pm.mode[0];
+        pm.left[3] = pm.mode[2];  pm.above[3] = pm.mode[1];
+    }
+    HvTokRing w = hv_tok_ring(S, gtok + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT);
+    S.shdr[t][0] = (u16)hv_tokenize_cu(w, cu.n, cu.lg, kind, L.split_inc, pm);
+}
+
 /* candidates of one CU after their TU jobs: engine state from the entry snapshot, binarisation, linking */
 static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu cu, int phases) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, n = cu.n;
@@ -1292,8 +1381,6 @@ static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu
     HV_GLOBAL u16 *gtok = (HV_GLOBAL u16 *)(scr + HV_TL * 1024 * 3);
     HV_GLOBAL u16 *gstream = gtok + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT;
     const int ntrials = (n == 8) ? 71 : 70;
-    const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
-    const int split_inc = L.split_inc, ml = L.ml, ma = L.ma;
     HV_PROF_T0();
     /* candidates start from the CU's entry snapshot  [ref :1423-1424] */
     for (int k = tid; k < HEVCE_NCTXP * HV_TL; k += HV_NTHREADS) L.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[cu.lvl][k / HV_TL];
@@ -1304,45 +1391,25 @@ static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu
        slot f of candidate t: f = 0 CU header; then per transform block (1 for candidates 0..34, 4 otherwise) a header slot
        followed by its 4x4 groups from the highest scan index down -- the order the engine consumes them.  Work items are
        dense and grouped by kind so that the threads of a wavefront execute the same binarisation path. */
-    {
-        const int h = n >> 1, ncg_cu = (n >> 2) * (n >> 2);
-        for (int item = tid; item < ntrials * ncg_cu; item += HV_NTHREADS) {          /* 4x4 group slots */
-            const int t = item / ncg_cu, gi = item % ncg_cu;
-            const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
-            const int tn = kind == 0 ? n : h, tlg = kind == 0 ? cu.lg : cu.lg - 1, ncgt = (tn >> 2) * (tn >> 2);
-            const int tu = gi / ncgt, r = gi % ncgt, cg = ncgt - 1 - r;
-            HV_GLOBAL u16 *slot = gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt) + 1 + r) * HV_SLOT;
-            u16 &sh = S.shdr[t][1 + tu * (1 + ncgt) + 1 + r];
-            if (!L.tinfo[t][tu].cbf) { sh = 0; continue; }
-            const int md = kind == 0 ? t : kind == 1 ? t - 35 : S.nxn_modes[tu];
-            if (kind == 2) sh = (u16)hv_tokenize_cg(S, slot, (const HV_LDSP short *)&S.nxn_bestlev[tu][0], tn, tlg, hv_scan_kind(tn, md), cg, L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig);
-            else sh = (u16)hv_tokenize_cg(S, slot, (const HV_GLOBAL short *)(glev + t * 1024 + tu * tn * tn + cg * 16), tn, tlg, hv_scan_kind(tn, md), cg, L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig);
-        }
+    if (n == 8) {
+        /* 280 group items on wavefronts 0..4; wavefronts 5..7 meanwhile: 179 block headers, 71 CU headers and the four
+           groups of the NxN candidate (levels in LDS, a different instantiation -- kept off the wavefronts above) */
+        if (tid < 280) hv_bin_group(S, L, cu, gtok, glev, tid >> 2, tid & 3);
         HV_PROF3L(0);
-        for (int item = tid; item < ntrials * 4; item += HV_NTHREADS) {               /* transform-block header slots */
-            const int t = item >> 2, tu = item & 3;
-            const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
-            if (kind == 0 && tu > 0) continue;
-            const int tn = kind == 0 ? n : h, tlg = kind == 0 ? cu.lg : cu.lg - 1, ncgt = (tn >> 2) * (tn >> 2);
-            const int md = kind == 0 ? t : kind == 1 ? t - 35 : S.nxn_modes[tu];
-            HV_GLOBAL u16 *slot = gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt)) * HV_SLOT;
-            S.shdr[t][1 + tu * (1 + ncgt)] = (u16)hv_tokenize_tu(S, slot, tn, tlg, hv_scan_kind(tn, md), 1, kind == 0 ? CX_YCBF + 1 : CX_YCBF, L.tinfo[t][tu].cbf, L.tinfo[t][tu].last);
+        const int w = tid - 320;
+        if (w >= 8 && w < 8 + 179) {
+            const int j = w - 8;
+            hv_bin_tu_header(S, L, cu, gtok, j < 35 ? j : 35 + ((j - 35) >> 2), j < 35 ? 0 : ((j - 35) & 3));
         }
-        for (int t = tid; t < ntrials; t += HV_NTHREADS) {                            /* CU header slots */
-            const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
-            HvModes pm;
-            for (int s4 = 0; s4 < 4; s4++) { pm.mode[s4] = 0; pm.left[s4] = 0; pm.above[s4] = 0; }
-            pm.left[0] = ml; pm.above[0] = ma;
-            if (kind == 0) pm.mode[0] = t;
-            else if (kind == 1) pm.mode[0] = t - 35;
-            else {
-                for (int s4 = 0; s4 < 4; s4++) pm.mode[s4] = S.nxn_modes[s4];
-                pm.left[1] = pm.mode[0];  pm.above[1] = S.map_pm[my - 1][mx + 1];                 /* [ref :1531-1538] */
-                pm.left[2] = S.map_pm[my + 1][mx - 1];  pm.above[2] = pm.mode[0];
-                pm.left[3] = pm.mode[2];  pm.above[3] = pm.mode[1];
-            }
-            S.shdr[t][0] = (u16)hv_tokenize_cu(gtok + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT, n, cu.lg, kind, split_inc, pm);
-        }
+        if (w >= 0 && w < 71) hv_bin_cu_header(S, L, cu, gtok, w);
+        if (w >= 188) hv_bin_group_nxn(S, L, cu, gtok, w - 188);
+    } else {
+        const int ncg_cu = (n >> 2) * (n >> 2);
+        for (int item = tid; item < 70 * ncg_cu; item += HV_NTHREADS) hv_bin_group(S, L, cu, gtok, glev, item / ncg_cu, item % ncg_cu);
+        HV_PROF3L(0);
+        for (int item = tid; item < 35 * 5; item += HV_NTHREADS)
+            hv_bin_tu_header(S, L, cu, gtok, item < 35 ? item : 35 + ((item - 35) >> 2), item < 35 ? 0 : ((item - 35) & 3));
+        for (int t = tid; t < 70; t += HV_NTHREADS) hv_bin_cu_header(S, L, cu, gtok, t);
     }
     BLOCK_SYNC();
     HV_PROF3L(1);
