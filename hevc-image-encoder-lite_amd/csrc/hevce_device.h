@@ -53,6 +53,8 @@ static HD void hv_atomic_min(int *p, int v) { atomicMin(p, v); }
 static HD int  hv_peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 static HD int  hv_mul24(int a, int b) { return __mul24(a, b); }
 static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v == 0 */
+static HD unsigned long long hv_ballot(int p) { return __ballot(p); }   /* one bit per active lane */
+static HD int  hv_clzll(unsigned long long v) { return __clzll((long long)v); }
 #endif
 
 /* diagnostics: -DHEVCE_TRACE makes lane 0 of every wavefront publish its last checkpoint to host-pinned memory */
@@ -167,14 +169,16 @@ struct alignas(16) HvLds {
     struct Level {
         u8  tctx[HEVCE_NCTXP][HV_TL];                       /* context bytes, one column per candidate */
         HevceCoderRegs tregs[HV_TL];
-        int tcost[HV_TL], tsse[HV_TL], tlen[HV_TL], tpos[HV_TL];
+        int tcost[HV_TL], tsse[HV_TL];
+        int tlen[HV_TL], tpos[HV_TL];                       /* list entries; position (entry | chunk << 8), -1 = finished / abandoned */
         HvTuInfo tinfo[HV_TL][4];
         u8  tdead[HV_TL];                                   /* abandoned: partial cost already above best_cost */
         int best_cost;                                      /* lowest cost of a COMPLETED candidate (pruning bound) */
-        int quota;                                          /* tokens a parent candidate advances per child phase */
+        int quota;                                          /* chunks a parent candidate advances per child phase */
         int split_inc, ml, ma;                              /* neighbour context read at the CU's entry [ref :1369-1373] */
     } lv[3];
-    u16 shdr[HV_TL][HEVCE_TOKEN_SLOTS + 2];                 /* slot headers, then (offset | g1 << 15) after linking */
+    u8  shdr[HV_TL][HEVCE_TOKEN_SLOTS + 2];                 /* chunks per slot of the level being prepared (transient) */
+    u16 slist0[HV_TL][10], slist1[HV_TL][22], slist2[HV_TL][70];   /* per level and candidate: non-empty slots, slot | chunks << 8 */
     /* NxN sub-search */
     short nxn_lev[35][16];
     u8    nxn_rec[35][16];
@@ -352,36 +356,23 @@ static HD void hv_terminate(HvCod &c, int bin) {                                
 /* stream: all lanes run the same instructions (no per-candidate control flow), which is what a      */
 /* 64-wide wavefront needs.  The reference interleaves both (HEVCe.c:943-1340 call CABACputBin*).    */
 /*                                                                                                  */
-/*   token, context bin : bit15=0, bits0-6 context index, bit7 bin value,                            */
-/*                        bit13 / bit14: add 4 / 1 to the index when the previous coded group had a   */
-/*                        level > 1 among its first eight (greater1 / greater2 context sets)          */
-/*   token, bypass chunk: bit15=1, bits8-11 length (1..8), bits0-7 bins  -- one token per <=8-bit      */
-/*                        chunk, exactly the chunks reference CABACputBins makes (HEVCe.c:899-911)    */
-/*   slot header (word 0): bits0-7 token count, bit8 group had non-zero levels, bit9 its greater1     */
-/*                        outcome (c1 == 0), bit10 start of a transform block (resets that memory)    */
+/*   token, context bin : bit15=0, bit14 = bin value, bits0-12 = byte offset of the context inside the         */
+/*                        candidate's context column (index * HV_TL); the greater1 / greater2 context sets   */
+/*                        already include the "previous group had a level > 1" memory                        */
+/*   token, bypass chunk: bit15=1, bits8-11 length (0..8), bits0-7 bins  -- one token per <=8-bit chunk,      */
+/*                        exactly the chunks reference CABACputBins makes (HEVCe.c:899-911); length 0 = no-op */
+/*   A slot in HBM is padded with no-ops to whole 16-byte chunks (8 tokens); the engine walks the candidate's  */
+/*   non-empty slots in order (list in LDS), so no contiguous copy of the stream is ever made.                */
 /* --------------------------------------------------------------------------------------------- */
 #define HV_SLOT        HEVCE_TOKEN_SLOT_WORDS /* 16-bit words per slot: header + up to 127 tokens (a group needs <= 109) */
 #define HV_SLOTS_TRIAL HEVCE_TOKEN_SLOTS                     /* CU header + at most 4 x (1 + 16) or 1 + 64 block/group slots            */
 #define HV_TOK_BYP     0x8000
-#define HV_TOK_G4      0x2000
-#define HV_TOK_G1      0x4000
-#define HV_HDR_NZ      0x100
-#define HV_HDR_G1      0x200
-#define HV_HDR_RESET   0x400
+#define HV_TOK_NOP     HV_TOK_BYP
+#define HV_CT(idx, bin) (((idx) * HV_TL) | ((bin) ? 0x4000 : 0))   /* context-coded bin */
 
 typedef unsigned HvChunk __attribute__((vector_size(16)));   /* eight 16-bit tokens, loaded as one dwordx4 */
 template <typename P> struct HvTokW { P p; int n; };
 #define HV_SLOT_TOK0 8                      /* tokens start 16 bytes into the slot so that chunks of 8 load as one dwordx4 */
-template <typename P> static HD void hv_tok_ctx(HvTokW<P> &w, int ctx, int bin) { w.p[HV_SLOT_TOK0 + w.n] = (u16)(ctx | (bin ? 0x80 : 0)); w.n++; }
-template <typename P> static HD void hv_tok_byp(HvTokW<P> &w, int bins, int len) {                                                 /* [ref :899-911] */
-    bins &= (1 << len) - 1;
-    while (len > 0) {
-        const int n = hv_min(len, 8);
-        len -= n;
-        w.p[HV_SLOT_TOK0 + w.n] = (u16)(HV_TOK_BYP | (n << 8) | ((bins >> len) & ((1 << n) - 1)));
-        w.n++;
-    }
-}
 
 static HD void hv_mpm(int left, int above, int out[3]) {                                                   /* [ref :958-977] */
     if (left != above) {
@@ -399,7 +390,7 @@ struct HvModes { int mode[4], left[4], above[4]; };
    HvTokW<P>: direct stores (slots in LDS: the NxN sub-search). */
 template <typename P> static HD void hv_emit(HvTokW<P> &w, int tok, int on) { w.p[HV_SLOT_TOK0 + w.n] = (u16)tok; w.n += on; }
 template <typename P> static HD void hv_tok_checkpoint(HvTokW<P> &) { }
-template <typename P> static HD int  hv_tok_finish(HvTokW<P> &w, int hdr) { w.p[0] = (u16)(w.n | hdr); return w.n | hdr; }
+template <typename P> static HD int  hv_tok_finish(HvTokW<P> &w) { return w.n; }                /* tokens */
 
 /* Writer for slots in HBM.  Sixty-four lanes storing single 16-bit tokens into sixty-four different slots cost one
    memory transaction per lane and token (measured: 60 % of the binarisation time).  Tokens therefore go to a small ring
@@ -429,17 +420,19 @@ static HD void hv_tok_checkpoint(HvTokRing &w) {
     if (w.n - w.fl >= 8) hv_tok_flush_chunk(w);
     if (w.n - w.fl >= 8) hv_tok_flush_chunk(w);
 }
-static HD int hv_tok_finish(HvTokRing &w, int hdr) {          /* after a checkpoint: fewer than 8 tokens are pending */
-    hv_tok_flush_chunk(w);
-    return w.n | hdr;
+static HD int hv_tok_finish(HvTokRing &w) {                   /* after a checkpoint: fewer than 8 tokens are pending */
+#pragma unroll
+    for (int i = 0; i < 7; i++) ((HV_LDSP u16 *)(w.ring + (((w.n + i) >> 1) & 15) * 64))[(w.n + i) & 1] = (u16)HV_TOK_NOP;
+    hv_tok_flush_chunk(w);                                    /* the last chunk, padded with no-ops */
+    return (w.n + 7) >> 3;                                    /* chunks */
 }
 
 /* CU header slot: split_cu_flag=0, part_mode, luma modes (all prev_intra_luma_pred_flags first, then mpm_idx /
    rem_intra_luma_pred_mode), chroma mode, split_transform_flag, cbf_cb, cbf_cr   [ref :943-1033, 1282-1287]
    Straight-line: every possible token is stored, the write position advances only for the ones that exist. */
 template <typename WR> static HD int hv_tokenize_cu(WR &w, int n, int lg, int kind, int split_inc, const HvModes &pm) {
-    hv_emit(w, CX_SPLIT_CU + split_inc, n >= 16);
-    hv_emit(w, CX_PART | (kind != 2 ? 0x80 : 0), n == 8);
+    hv_emit(w, HV_CT(CX_SPLIT_CU + split_inc, 0), n >= 16);
+    hv_emit(w, HV_CT(CX_PART, kind != 2), n == 8);
     const int parts = kind == 2 ? 4 : 1;
     int hit[4], rem[4];
 #pragma unroll
@@ -452,7 +445,7 @@ template <typename WR> static HD int hv_tokenize_cu(WR &w, int n, int lg, int ki
         int r = md;                                            /* skip the candidates from the largest down */
         r -= (r > hi); r -= (r > mid); r -= (r > lo);
         hit[i] = h; rem[i] = r;
-        hv_emit(w, CX_YPM | (h >= 0 ? 0x80 : 0), i < parts);
+        hv_emit(w, HV_CT(CX_YPM, h >= 0), i < parts);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -461,12 +454,12 @@ template <typename WR> static HD int hv_tokenize_cu(WR &w, int n, int lg, int ki
         hv_emit(w, HV_TOK_BYP | (1 << 8) | ((hit[i] - 1) & 1), on && hit[i] > 0);
         hv_emit(w, HV_TOK_BYP | (5 << 8) | (rem[i] & 31), on && !ishit);
     }
-    hv_emit(w, CX_UVPM, 1);
-    hv_emit(w, (CX_SPLIT_TU + (5 - lg)) | (kind == 1 ? 0x80 : 0), kind != 2);
-    hv_emit(w, CX_UVCBF, 1);
-    hv_emit(w, CX_UVCBF, 1);
+    hv_emit(w, HV_CT(CX_UVPM, 0), 1);
+    hv_emit(w, HV_CT(CX_SPLIT_TU + (5 - lg), kind == 1), kind != 2);
+    hv_emit(w, HV_CT(CX_UVCBF, 0), 1);
+    hv_emit(w, HV_CT(CX_UVCBF, 0), 1);
     hv_tok_checkpoint(w);
-    return hv_tok_finish(w, 0);
+    return hv_tok_finish(w);
 }
 
 /* last_sig_coeff prefix group of a coordinate and the smallest coordinate of a group, in closed form
@@ -477,7 +470,7 @@ static HD int hv_last_min(int g) { return g < 4 ? g : (2 + (g & 1)) << ((g >> 1)
 /* TU header slot: cbf_luma (unless the caller is the NxN sub-search, which codes bare residuals) and the position of
    the last significant coefficient   [ref :1038-1087, 1192].  Straight-line like the CU header (<= 25 tokens). */
 template <typename WR> static HD int hv_tokenize_tu(const HvLds &S, WR &w, int n, int lg, int kind_scan, int with_cbf, int cbf_ctx, int cbf, int last) {
-    hv_emit(w, cbf_ctx | (cbf ? 0x80 : 0), with_cbf);
+    hv_emit(w, HV_CT(cbf_ctx, cbf), with_cbf);
     const int on0 = cbf || !with_cbf;
     int gy, gx, iy, ix;
     hv_scan_cg(S, lg, kind_scan, last >> 4, gy, gx);
@@ -487,11 +480,11 @@ template <typename WR> static HD int hv_tokenize_tu(const HvLds &S, WR &w, int n
     int ty = kind_scan == 2 ? x : y, tx = kind_scan == 2 ? y : x;
     const int ggy = hv_last_group(ty), ggx = hv_last_group(tx), gmax = 2 * lg - 1;       /* gmax = group of n - 1 */
 #pragma unroll
-    for (int i = 0; i < 9; i++) hv_emit(w, (CX_LASTX + 5 * cls + (i >> sh)) | 0x80, on0 && i < ggx);
-    hv_emit(w, CX_LASTX + 5 * cls + (ggx >> sh), on0 && ggx < gmax);
+    for (int i = 0; i < 9; i++) hv_emit(w, HV_CT(CX_LASTX + 5 * cls + (i >> sh), 1), on0 && i < ggx);
+    hv_emit(w, HV_CT(CX_LASTX + 5 * cls + (ggx >> sh), 0), on0 && ggx < gmax);
 #pragma unroll
-    for (int i = 0; i < 9; i++) hv_emit(w, (CX_LASTY + 5 * cls + (i >> sh)) | 0x80, on0 && i < ggy);
-    hv_emit(w, CX_LASTY + 5 * cls + (ggy >> sh), on0 && ggy < gmax);
+    for (int i = 0; i < 9; i++) hv_emit(w, HV_CT(CX_LASTY + 5 * cls + (i >> sh), 1), on0 && i < ggy);
+    hv_emit(w, HV_CT(CX_LASTY + 5 * cls + (ggy >> sh), 0), on0 && ggy < gmax);
     const int nx = ggx > 3 ? ((ggx - 2) >> 1) : 0, ny = ggy > 3 ? ((ggy - 2) >> 1) : 0;   /* suffix bits, one chunk per bit */
     tx -= hv_last_min(ggx); ty -= hv_last_min(ggy);
 #pragma unroll
@@ -499,7 +492,7 @@ template <typename WR> static HD int hv_tokenize_tu(const HvLds &S, WR &w, int n
 #pragma unroll
     for (int i = 2; i >= 0; i--) hv_emit(w, HV_TOK_BYP | (1 << 8) | ((ty >> i) & 1), on0 && i < ny);
     hv_tok_checkpoint(w);
-    return hv_tok_finish(w, HV_HDR_RESET);
+    return hv_tok_finish(w);
 }
 
 static HD int hv_sigctx(int n, int diag, int y, int x, int nb) {                                           /* [ref :1092-1122] */
@@ -546,53 +539,71 @@ template <typename WR> static HD void hv_emit_remainder(WR &w, int v, int k, int
 
 /* one 4x4 coefficient group of a transform block whose levels lie in SCAN ORDER at lev16[0..15]   [ref :1194-1268]
    cg = the group's index in scan order; last / cgsig describe the whole block (from the TU job).
+   Two steps: hv_cg_load() fetches the levels and derives what the NEXT coded group must know (g1own: one of the first
+   eight non-zero levels is > 1, which bumps that group's greater1/greater2 context sets  [ref :1222-1226]);
+   hv_cg_emit() writes the tokens, given that fact about the PREVIOUS coded group (g1).
    Straight-line code: fixed trip counts, unconditional stores, conditional counts -- threads binarising different groups
    stay converged and nothing is a branch. */
-template <typename WR, typename LP> static HD int hv_tokenize_cg(const HvLds &S, WR &w, LP lev16, int n, int lg, int kind, int cg, int last, u64 cgsig) {
+struct HvCg { int v[16]; unsigned nzm; int coded, cgs, nb, first_cg, at_last_cg, start, n, kind, g1own; };
+template <typename LP> static HD void hv_cg_load(const HvLds &S, HvCg &g, LP lev16, int n, int lg, int kind, int cg, int last, u64 cgsig, int valid) {
     const int cg_last = last >> 4;
-    int hdr = 0;
-    if (cg <= cg_last) {
-        int gy, gx;
-        hv_scan_cg(S, lg, kind, cg, gy, gx);
-        const int ncg = n >> 2, first_cg = (cg == 0), at_last_cg = (cg == cg_last);
-        const int cgs = (int)((cgsig >> (gy * 8 + gx)) & 1);
-        const int right = (gx < ncg - 1) ? (int)((cgsig >> (gy * 8 + gx + 1)) & 1) : 0;
-        const int below = (gy < ncg - 1) ? (int)((cgsig >> (gy * 8 + 8 + gx)) & 1) : 0;
-        const int nb = (below << 1) | right;
-        hv_emit(w, (CX_SIGCG + (nb != 0)) | (cgs ? 0x80 : 0), !first_cg && !at_last_cg);
-        if (cgs || first_cg) {
-            const int start = at_last_cg ? (last & 15) : 15;
-            int v[16];
-            unsigned nzm = 0;
+    int gy, gx;
+    hv_scan_cg(S, lg, kind, cg, gy, gx);
+    const int ncg = n >> 2;
+    g.n = n; g.kind = kind;
+    g.coded = valid && cg <= cg_last;
+    g.first_cg = (cg == 0); g.at_last_cg = (cg == cg_last);
+    g.cgs = g.coded ? (int)((cgsig >> (gy * 8 + gx)) & 1) : 0;
+    const int right = (gx < ncg - 1) ? (int)((cgsig >> (gy * 8 + gx + 1)) & 1) : 0;
+    const int below = (gy < ncg - 1) ? (int)((cgsig >> (gy * 8 + 8 + gx)) & 1) : 0;
+    g.nb = (below << 1) | right;
+    g.start = g.at_last_cg ? (last & 15) : 15;
+    unsigned nzm = 0, bigm = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) { v[k] = cgs ? (int)lev16[k] : 0; nzm |= (unsigned)(v[k] != 0) << k; }
-            const u8 *tab = S.sigtab[hv_sigtab_index(n, kind, nb, first_cg)];
+    for (int k = 0; k < 16; k++) {
+        g.v[k] = g.cgs ? (int)lev16[k] : 0;
+        nzm |= (unsigned)(g.v[k] != 0) << k;
+        bigm |= (unsigned)(hv_abs(g.v[k]) > 1) << k;
+    }
+    g.nzm = nzm;
+    unsigned m8 = nzm;                                         /* the eight non-zero levels coded first = highest scan positions */
+#pragma unroll
+    for (int i = 0; i < 8; i++) m8 = (__builtin_popcount(m8) > 8) ? (m8 & (m8 - 1)) : m8;
+    g.g1own = (bigm & m8) != 0;
+}
+template <typename WR> static HD int hv_cg_emit(const HvLds &S, WR &w, const HvCg &g, int g1) {
+    if (g.coded) {
+        const int first_cg = g.first_cg, at_last_cg = g.at_last_cg, cgs = g.cgs, start = g.start;
+        const unsigned nzm = g.nzm;
+        hv_emit(w, HV_CT(CX_SIGCG + (g.nb != 0), cgs), !first_cg && !at_last_cg);
+        if (cgs || first_cg) {
+            const u8 *tab = S.sigtab[hv_sigtab_index(g.n, g.kind, g.nb, first_cg)];
             /* significance flags, highest scan position first; position 0 of a later group is inferred when nothing else is set */
             const int any_above0 = (nzm >> 1) != 0;
 #pragma unroll
             for (int ii = 15; ii >= 0; ii--) {
                 const int on = (ii <= start) && !(at_last_cg && ii == start) && (ii != 0 || first_cg || any_above0);
-                hv_emit(w, (CX_SIG + tab[ii]) | ((nzm >> ii) & 1 ? 0x80 : 0), on);
+                hv_emit(w, HV_CT(CX_SIG + tab[ii], (nzm >> ii) & 1), on);
             }
             hv_tok_checkpoint(w);                                  /* <= 17 tokens so far */
             const int nz = __builtin_popcount(nzm);
             /* greater1 flags of the first eight non-zero levels, one greater2 flag; sign bits in the same order */
-            const int set4 = (first_cg ? 0 : 8), set1 = (first_cg ? 0 : 2);
+            const int set4 = (first_cg ? 0 : 8) + (g1 ? 4 : 0), set1 = (first_cg ? 0 : 2) + (g1 ? 1 : 0);
             int esc = nz > 8, g2 = -1, c1 = 1, j = 0, signs = 0;
 #pragma unroll
             for (int ii = 15; ii >= 0; ii--) {
                 const int isnz = (nzm >> ii) & 1;
-                const int a = hv_abs(v[ii]), on = isnz && j < 8, big = a > 1;
-                hv_emit(w, (CX_ONE + set4 + c1) | (big ? 0x80 : 0) | HV_TOK_G4, on);
+                const int a = hv_abs(g.v[ii]), on = isnz && j < 8, big = a > 1;
+                hv_emit(w, HV_CT(CX_ONE + set4 + c1, big), on);
                 const int first_big = on && big && g2 < 0, more_big = on && big && g2 >= 0;
                 g2 = first_big ? (a > 2) : g2;
                 esc |= more_big;
                 c1 = (on && big) ? 0 : ((on && c1 > 0 && c1 < 3) ? c1 + 1 : c1);
-                signs = isnz ? ((signs << 1) | (v[ii] < 0)) : signs;
+                signs = isnz ? ((signs << 1) | (g.v[ii] < 0)) : signs;
                 j += isnz;
             }
             const int has_g2 = nz > 0 && c1 == 0 && g2 >= 0;
-            hv_emit(w, (CX_ABS + set1) | (g2 > 0 ? 0x80 : 0) | HV_TOK_G1, has_g2);
+            hv_emit(w, HV_CT(CX_ABS + set1, g2 > 0), has_g2);
             esc |= has_g2 && g2 > 0;
             hv_emit_byp(w, signs, nz, nz > 0);
             /* remaining magnitudes with the adaptive Rice parameter */
@@ -601,7 +612,7 @@ template <typename WR, typename LP> static HD int hv_tokenize_cg(const HvLds &S,
 #pragma unroll
             for (int ii = 15; ii >= 0; ii--) {
                 const int isnz = (nzm >> ii) & 1;
-                const int a = hv_abs(v[ii]), rem = a - (j < 8 ? base : 1);
+                const int a = hv_abs(g.v[ii]), rem = a - (j < 8 ? base : 1);
                 const int on = isnz && esc && rem >= 0;
                 hv_emit_remainder(w, hv_max(rem, 0), rice, on);
                 rice = (on && a > (3 << rice)) ? hv_min(rice + 1, 4) : rice;
@@ -609,30 +620,18 @@ template <typename WR, typename LP> static HD int hv_tokenize_cg(const HvLds &S,
                 j += isnz;
                 if ((ii & 3) == 2) hv_tok_checkpoint(w);          /* <= 11 + 2 x 5, then <= 4 x 5 tokens per section */
             }
-            hdr = nz > 0 ? (HV_HDR_NZ | (c1 == 0 ? HV_HDR_G1 : 0)) : 0;
         }
     }
     hv_tok_checkpoint(w);
-    return hv_tok_finish(w, hdr);
+    return hv_tok_finish(w);
 }
 
-/* Final token format in a LINKED stream (one contiguous stream per candidate, see hv_link_*):
-     context bin : bit15=0, bit14 = bin value, bits0-12 = byte offset of the context inside the candidate's column
-                   (index * HV_TL), with the greater1/greater2 set memory already resolved
-     bypass chunk: bit15=1, bits8-11 length, bits0-7 bins (length 0 = no-op padding)                              */
 #define HV_CX(i) (cx + (i) * HV_TL)
-#define HV_TOK_NOP HV_TOK_BYP
 static HD int hv_chunk_get(const HvChunk &c, int i) {
     const unsigned lo = (i & 4) ? c[2] : c[0], hi = (i & 4) ? c[3] : c[1];
     const unsigned d = (i & 2) ? hi : lo;
     return (int)((d >> ((i & 1) << 4)) & 0xffffu);
 }
-static HD int hv_link_token(int tok, int g1) {
-    if (tok & HV_TOK_BYP) return tok;
-    const int idx = (tok & 0x7f) + (g1 ? (((tok >> 13) & 1) << 2) + ((tok >> 14) & 1) : 0);
-    return (idx * HV_TL) | (((tok >> 7) & 1) << 14);
-}
-
 /* The arithmetic engine of one candidate over tokens [i0, i1) of its linked stream (chunk pointer, 16-byte aligned);
    resumable: the coder registers and the position are all the state there is.
    cx = &S.tctx[0][trial].  All lanes of a wavefront run this loop in lockstep; one iteration = one token through the
@@ -691,6 +690,46 @@ static HD int hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int i0, i
             cp = cpn; tok = tn;
         }
         if (best && (base & 8) && hv_rdcost(q, sse, hv_cod_bits(c) - bits0) > hv_peek(best)) return 1;
+    }
+    return 0;
+}
+
+/* The same engine over a candidate's SLOTS in HBM: ls[0..nlist) lists its non-empty slots in coding order as
+   (slot index | chunks << 8); (k, ci) = list entry and chunk inside that slot where work continues -- together with the
+   coder registers that is all the state, so a candidate can be advanced `budget` chunks at a time.  Slots are whole
+   chunks (padded with no-op tokens), so no token needs a range check.  Returns 1 when abandoned. */
+static HD int hv_engine_slots(const HvLds &S, HvCod &c, u8 *cx, const HV_GLOBAL u16 *slots, const HV_LDSP u16 *ls, int nlist, int &k, int &ci,
+                              int budget, int q, int sse, int bits0, const int *best) {
+    int e = ls[hv_min(k, nlist - 1)];
+    int nch = e >> 8;
+    const HV_GLOBAL HvChunk *ptr = (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HV_SLOT + HV_SLOT_TOK0) + ci;
+    HvChunk nxt = *ptr;
+    int it = 0;
+    while (budget > 0 && k < nlist) {
+        const HvChunk cur = nxt;
+        ci++;                                                     /* where the chunk after this one lives; request it now */
+        const int adv = ci >= nch;
+        k += adv;
+        e = ls[hv_min(k, nlist - 1)];
+        ci = adv ? 0 : ci;
+        nch = adv ? (e >> 8) : nch;
+        ptr = adv ? (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HV_SLOT + HV_SLOT_TOK0) : ptr + 1;
+        nxt = *ptr;
+        int tok = (int)(cur[0] & 0xffffu);
+        u8 *cp = hv_tok_ctx_ptr(cx, tok);
+        int cv = *cp & 0x7f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int tn = HV_TOK_NOP;
+            if (j < 7) tn = (int)((cur[(j + 1) >> 1] >> (((j + 1) & 1) << 4)) & 0xffffu);
+            u8 *cpn = hv_tok_ctx_ptr(cx, tn);
+            const int cvl = *cpn & 0x7f;
+            const int ncv = hv_engine_step(S, c, cp, cv, tok);
+            cv = (cpn == cp) ? ncv : cvl;
+            cp = cpn; tok = tn;
+        }
+        budget--; it++;
+        if (best && !(it & 1) && hv_rdcost(q, sse, hv_cod_bits(c) - bits0) > hv_peek(best)) return 1;
     }
     return 0;
 }
@@ -1220,10 +1259,11 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
             const int ks = hv_scan_kind(4, lane);
             /* the two slots are laid out so that their tokens are contiguous from tk[8]; one group: no set memory */
             HvTokW<HV_LDSP u16 *> wa = { tk, 0 };
-            const int na = hv_tokenize_tu(S, wa, 4, 2, ks, 0, 0, 1, S.nxn_last[lane]) & 0xff;
+            const int na = hv_tokenize_tu(S, wa, 4, 2, ks, 0, 0, 1, S.nxn_last[lane]);
             HvTokW<HV_LDSP u16 *> wb = { tk + na, 0 };
-            const int nb = hv_tokenize_cg(S, wb, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0)) & 0xff;
-            for (int k = 0; k < na + nb; k++) tk[HV_SLOT_TOK0 + k] = (u16)hv_link_token(tk[HV_SLOT_TOK0 + k], 0);
+            HvCg g;
+            hv_cg_load(S, g, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0), 1);
+            const int nb = hv_cg_emit(S, wb, g, 0);
             HV_PROF2(S, 1);
             hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), 0, na + nb);
             cost = hv_rdcost(q, S.nxn_sse[lane], hv_cod_bits(c));
@@ -1328,30 +1368,48 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
 }
 
 /* binarisation work items of hv_prepare_streams (slot numbering: see there) */
-static HD void hv_bin_group(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, HvGLev glev, int t, int gi) {
+static HD HV_LDSP u16 *hv_slist(HvLds &S, int lvl, int t) { return lvl == 0 ? (HV_LDSP u16 *)S.slist0[t] : lvl == 1 ? (HV_LDSP u16 *)S.slist1[t] : (HV_LDSP u16 *)S.slist2[t]; }
+static HD const HV_LDSP u16 *hv_slist(const HvLds &S, int lvl, int t) { return lvl == 0 ? (const HV_LDSP u16 *)S.slist0[t] : lvl == 1 ? (const HV_LDSP u16 *)S.slist1[t] : (const HV_LDSP u16 *)S.slist2[t]; }
+
+/* Group item number `item` (candidate-major, coding order inside a transform block).  EVERY lane of the wavefront calls
+   this (valid = 0 beyond the last item): the groups of one transform block sit in adjacent lanes, aligned to their
+   count, so the "previous coded group had a level > 1" memory  [ref :1222-1226] is two wave-wide ballots away. */
+static HD void hv_bin_group(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, HvGLev glev, int item, int valid) {
+    const int ncg_cu = (cu.n >> 2) * (cu.n >> 2);
+    item = valid ? item : 0;
+    const int t = item / ncg_cu, gi = item % ncg_cu;
     const int kind = t < 35 ? 0 : 1;                             /* one block of the CU size / four of half the size */
     const int tn = kind == 0 ? cu.n : (cu.n >> 1), tlg = kind == 0 ? cu.lg : cu.lg - 1, ncgt = (tn >> 2) * (tn >> 2);
     const int tu = gi / ncgt, r = gi % ncgt, cg = ncgt - 1 - r;
-    u16 &sh = S.shdr[t][1 + tu * (1 + ncgt) + 1 + r];
-    if (!L.tinfo[t][tu].cbf) { sh = 0; return; }
+    const int cbf = valid && L.tinfo[t][tu].cbf;
+    HvCg g;
+    hv_cg_load(S, g, (const HV_GLOBAL short *)(glev + t * 1024 + tu * tn * tn + cg * 16), tn, tlg,
+               hv_scan_kind(tn, kind == 0 ? t : t - 35), cg, L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig, cbf);
+    const u64 bnz = hv_ballot(g.nzm != 0), bg1 = hv_ballot(g.g1own);
+    const int lane = hv_tid() & 63;
+    const u64 before = bnz & ((((u64)1 << (lane & (ncgt - 1))) - 1) << (lane & ~(ncgt - 1)));   /* coded earlier, same block */
+    const int g1 = before ? (int)((bg1 >> (63 - hv_clzll(before))) & 1) : 0;
+    if (!valid) return;
+    u8 &sh = S.shdr[t][1 + tu * (1 + ncgt) + 1 + r];
+    if (!cbf) { sh = 0; return; }
     HvTokRing w = hv_tok_ring(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt) + 1 + r) * HV_SLOT);
-    sh = (u16)hv_tokenize_cg(S, w, (const HV_GLOBAL short *)(glev + t * 1024 + tu * tn * tn + cg * 16), tn, tlg,
-                             hv_scan_kind(tn, kind == 0 ? t : t - 35), cg, L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig);
+    sh = (u8)hv_cg_emit(S, w, g, g1);
 }
 static HD void hv_bin_group_nxn(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, int tu) {   /* candidate 70: levels in LDS */
     const int t = 70;
-    u16 &sh = S.shdr[t][1 + tu * 2 + 1];
+    u8 &sh = S.shdr[t][1 + tu * 2 + 1];
     if (!L.tinfo[t][tu].cbf) { sh = 0; return; }
     HvTokRing w = hv_tok_ring(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * 2 + 1) * HV_SLOT);
-    sh = (u16)hv_tokenize_cg(S, w, (const HV_LDSP short *)&S.nxn_bestlev[tu][0], 4, 2, hv_scan_kind(4, S.nxn_modes[tu]), 0,
-                             L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig);
+    HvCg g;
+    hv_cg_load(S, g, (const HV_LDSP short *)&S.nxn_bestlev[tu][0], 4, 2, hv_scan_kind(4, S.nxn_modes[tu]), 0, L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig, 1);
+    sh = (u8)hv_cg_emit(S, w, g, 0);
 }
 static HD void hv_bin_tu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, int t, int tu) {
     const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
     const int tn = kind == 0 ? cu.n : (cu.n >> 1), tlg = kind == 0 ? cu.lg : cu.lg - 1, ncgt = (tn >> 2) * (tn >> 2);
     const int md = kind == 0 ? t : kind == 1 ? t - 35 : S.nxn_modes[tu];
     HvTokRing w = hv_tok_ring(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt)) * HV_SLOT);
-    S.shdr[t][1 + tu * (1 + ncgt)] = (u16)hv_tokenize_tu(S, w, tn, tlg, hv_scan_kind(tn, md), 1, kind == 0 ? CX_YCBF + 1 : CX_YCBF,
+    S.shdr[t][1 + tu * (1 + ncgt)] = (u8)hv_tokenize_tu(S, w, tn, tlg, hv_scan_kind(tn, md), 1, kind == 0 ? CX_YCBF + 1 : CX_YCBF,
                                                          L.tinfo[t][tu].cbf, L.tinfo[t][tu].last);
 }
 static HD void hv_bin_cu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, int t) {
@@ -1369,7 +1427,7 @@ static HD void hv_bin_cu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GL
         pm.left[3] = pm.mode[2];  pm.above[3] = pm.mode[1];
     }
     HvTokRing w = hv_tok_ring(S, gtok + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT);
-    S.shdr[t][0] = (u16)hv_tokenize_cu(w, cu.n, cu.lg, kind, L.split_inc, pm);
+    S.shdr[t][0] = (u8)hv_tokenize_cu(w, cu.n, cu.lg, kind, L.split_inc, pm);
 }
 
 /* candidates of one CU after their TU jobs: engine state from the entry snapshot, binarisation, linking */
@@ -1379,7 +1437,6 @@ static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu
     HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
     HvGLev glev = (HvGLev)scr;
     HV_GLOBAL u16 *gtok = (HV_GLOBAL u16 *)(scr + HV_TL * 1024 * 3);
-    HV_GLOBAL u16 *gstream = gtok + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT;
     const int ntrials = (n == 8) ? 71 : 70;
     HV_PROF_T0();
     /* candidates start from the CU's entry snapshot  [ref :1423-1424] */
@@ -1394,7 +1451,7 @@ static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu
     if (n == 8) {
         /* 280 group items on wavefronts 0..4; wavefronts 5..7 meanwhile: 179 block headers, 71 CU headers and the four
            groups of the NxN candidate (levels in LDS, a different instantiation -- kept off the wavefronts above) */
-        if (tid < 280) hv_bin_group(S, L, cu, gtok, glev, tid >> 2, tid & 3);
+        if (tid < 320) hv_bin_group(S, L, cu, gtok, glev, tid, tid < 280);
         HV_PROF3L(0);
         const int w = tid - 320;
         if (w >= 8 && w < 8 + 179) {
@@ -1405,7 +1462,7 @@ static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu
         if (w >= 188) hv_bin_group_nxn(S, L, cu, gtok, w - 188);
     } else {
         const int ncg_cu = (n >> 2) * (n >> 2);
-        for (int item = tid; item < 70 * ncg_cu; item += HV_NTHREADS) hv_bin_group(S, L, cu, gtok, glev, item / ncg_cu, item % ncg_cu);
+        for (int i0 = 0; i0 < 70 * ncg_cu; i0 += HV_NTHREADS) hv_bin_group(S, L, cu, gtok, glev, i0 + tid, i0 + tid < 70 * ncg_cu);
         HV_PROF3L(0);
         for (int item = tid; item < 35 * 5; item += HV_NTHREADS)
             hv_bin_tu_header(S, L, cu, gtok, item < 35 ? item : 35 + ((item - 35) >> 2), item < 35 ? 0 : ((item - 35) & 3));
@@ -1413,48 +1470,25 @@ static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu
     }
     BLOCK_SYNC();
     HV_PROF3L(1);
-    /* ---------------- link: slot offsets and greater1-set memory per candidate, then one contiguous stream each -------- */
+    /* ---------------- link: per candidate the list of its non-empty slots; the engine walks it ---------------- */
     for (int t = tid; t < ntrials; t += HV_NTHREADS) {
         const int nslots = hv_trial_slots(n, t);
-        int off = 0, g1 = 0;
+        HV_LDSP u16 *ls = hv_slist(S, cu.lvl, t);
+        int k = 0, tot = 0;
         for (int f = 0; f < nslots; f++) {
-            const int hdr = S.shdr[t][f];
-            if (hdr & HV_HDR_RESET) g1 = 0;
-            S.shdr[t][f] = (u16)(off | (g1 << 15));
-            if (hdr & HV_HDR_NZ) g1 = (hdr & HV_HDR_G1) ? 1 : 0;
-            off += hdr & 0xff;
+            const int ch = S.shdr[t][f];
+            ls[k] = (u16)(f | (ch << 8));
+            k += (ch != 0); tot += ch;
         }
-        S.shdr[t][nslots] = (u16)off;
-        L.tlen[t] = off;
+        L.tlen[t] = k; L.tpos[t] = 0;
+        L.tcost[t] = tot;                                        /* until the candidate completes: its length in chunks */
     }
     BLOCK_SYNC();
     HV_PROF3L(2);
-    /* copy: one wavefront per candidate walks its slots; lane k moves token k of the slot (coalesced 2-byte stores) */
-    for (int t = hv_uni(wave); t < ntrials; t += HV_NWAVES) {
-        const int nslots = hv_trial_slots(n, t);
-        HV_GLOBAL u16 *dst = gstream + (size_t)t * HEVCE_STREAM_WORDS;
-        const HV_GLOBAL u16 *src = gtok + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0;
-        for (int f0 = 0; f0 < nslots; f0 += 4) {                  /* four slots per iteration: their loads are in flight together */
-            int off[4], g1[4], cnt[4], tk[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int f = hv_min(f0 + u, nslots - 1);
-                const int o0 = S.shdr[t][f];
-                off[u] = o0 & 0x7fff; g1[u] = o0 >> 15;
-                cnt[u] = (f0 + u < nslots) ? (S.shdr[t][f + 1] & 0x7fff) - off[u] : 0;
-                tk[u] = (lane < cnt[u]) ? (int)src[f * HV_SLOT + lane] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (lane < cnt[u]) dst[off[u] + lane] = (u16)hv_link_token(tk[u], g1[u]);
-                for (int k = lane + 64; k < cnt[u]; k += 64) dst[off[u] + k] = (u16)hv_link_token(src[hv_min(f0 + u, nslots - 1) * HV_SLOT + k], g1[u]);
-            }
-        }
-    }
     if (tid == 0) {                                              /* slice size of a parent's candidates: done by its last child */
         int mx_len = 0;
-        for (int t = 0; t < ntrials; t++) mx_len = hv_max(mx_len, L.tlen[t]);
-        L.quota = (n == 8) ? 0x7fffffff : ((mx_len + phases - 1) / phases + 16);
+        for (int t = 0; t < ntrials; t++) mx_len = hv_max(mx_len, L.tcost[t]);
+        L.quota = (n == 8) ? 0x7fffffff : ((mx_len + phases - 1) / phases + 2);
     }
     BLOCK_SYNC();
     HV_PROF3L(3);
@@ -1470,25 +1504,24 @@ static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int
     if (lvl < 3 && ((mask >> lvl) & 1)) {
         HvLds::Level &L = S.lv[lvl];
         const int ntrials = (lvl == 0) ? 71 : 70;
-        if (t < ntrials && L.tpos[t] <= L.tlen[t]) {                       /* tpos == tlen + 1 marks finished / abandoned */
-            const int pos = L.tpos[t], len = L.tlen[t];
+        if (t < ntrials && L.tpos[t] >= 0) {
+            const int pos = L.tpos[t], nlist = L.tlen[t];
+            int k = pos & 0xff, ci = pos >> 8;
             HvCod c;
             hv_cod_load(c, L.tregs[t]);
             const int bits0 = hv_regs_bits(S.ent[lvl]);
-            const int end = (finish || lvl == 0) ? len : hv_min(len, pos + L.quota);
-            const HV_GLOBAL u16 *gstream = (const HV_GLOBAL u16 *)(hv_level_scratch(im, lvl) + HV_TL * 1024 * 3) + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT;
+            const int budget = (finish || lvl == 0) ? 0x7fffffff : L.quota;
+            const HV_GLOBAL u16 *slots = (const HV_GLOBAL u16 *)(hv_level_scratch(im, lvl) + HV_TL * 1024 * 3) + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT;
             int dead = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0) > hv_peek(&L.best_cost);
-            if (!dead && pos < end)
-                dead = hv_engine(S, c, &L.tctx[0][t], (const HV_GLOBAL HvChunk *)(gstream + (size_t)t * HEVCE_STREAM_WORDS), pos, end,
-                                 q, L.tsse[t], bits0, &L.best_cost);
+            if (!dead) dead = hv_engine_slots(S, c, &L.tctx[0][t], slots, hv_slist(S, lvl, t), nlist, k, ci, budget, q, L.tsse[t], bits0, &L.best_cost);
             hv_cod_store(L.tregs[t], c);
-            if (dead) { L.tdead[t] = 1; L.tcost[t] = HV_I32MAX; L.tpos[t] = len + 1; }
-            else if (end == len) {
+            if (dead) { L.tdead[t] = 1; L.tcost[t] = HV_I32MAX; L.tpos[t] = -1; }
+            else if (k >= nlist) {
                 const int cost = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0);
                 L.tcost[t] = cost;
-                L.tpos[t] = len + 1;
+                L.tpos[t] = -1;
                 hv_atomic_min(&L.best_cost, cost);
-            } else L.tpos[t] = end;
+            } else L.tpos[t] = k | (ci << 8);
         }
     }
     BLOCK_SYNC();

@@ -40,6 +40,16 @@ static inline int hv_bcast0(int v) {
     emu_wave_sync();
     return r;
 }
+static inline unsigned long long hv_ballot(int p) {         /* every lane of the wave must call it */
+    const int w = emu_cur >> 6, l = emu_cur & 63;
+    emu_stage[w][l] = p ? 1 : 0;
+    emu_wave_sync();
+    unsigned long long r = 0;
+    for (int i = 0; i < 64; i++) r |= (unsigned long long)emu_stage[w][i] << i;
+    emu_wave_sync();
+    return r;
+}
+static inline int hv_clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
 static inline int hv_atomic_inc(int *p) { return (*p)++; }
 static inline void hv_atomic_min(int *p, int v) { if (v < *p) *p = v; }
 static inline int hv_peek(const int *p) { return *p; }
