@@ -51,6 +51,8 @@ static HD int  hv_bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }   
 static HD int  hv_atomic_inc(int *p) { return atomicAdd(p, 1); }
 static HD void hv_atomic_min(int *p, int v) { atomicMin(p, v); }
 static HD int  hv_peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+static HD int  hv_poll(const int *p) { return hv_peek(p); }      /* value other wavefronts are changing meanwhile */
+static HD void hv_atomic_dec(int *p) { atomicSub(p, 1); }
 static HD int  hv_mul24(int a, int b) { return __mul24(a, b); }
 static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v == 0 */
 static HD unsigned long long hv_ballot(int p) { return __ballot(p); }   /* one bit per active lane */
@@ -72,7 +74,11 @@ static HD int  hv_clzll(unsigned long long v) { return __clzll((long long)v); }
 #define HV_PROF_T0()  unsigned long long pt_ = __builtin_amdgcn_s_memtime()
 #define HV_PROF2_T0() unsigned long long p2_ = __builtin_amdgcn_s_memtime()
 #define HV_PROF3(S, ph) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof2[ph] += n_ - pt_; pt_ = n_; } } while (0)
+#ifdef HEVCE_PROF_JOBS
+#define HV_PROF3L(k) do { if (cu.lvl == 0) HV_PROF3(S, 4 + (k)); } while (0)
+#else
 #define HV_PROF3L(k) HV_PROF3(S, 4 + 4 * cu.lvl + (k))
+#endif
 #define HV_PROF2(S, ph) do { if ((hv_tid() & 63) == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof2[ph] += n_ - p2_; p2_ = n_; } } while (0)
 #define HV_PROF(S, lvl, ph) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof[lvl][ph] += n_ - pt_; pt_ = n_; } } while (0)
 #else
@@ -150,8 +156,7 @@ struct alignas(16) HvLds {
     /* tables (copied from constant memory so that per-lane divergent lookups are LDS reads) */
     unsigned lps4[64];
     u8  lpsnext[64];
-    u16 lpsq[256];                                          /* [state*4 + (range>>6 & 3)] = LPS range | renormalisation shift << 8 */
-    u8  nxt_mps[128], nxt_lps[128];
+    alignas(8) unsigned ctab[128][2];                       /* [context byte]: { four LPS ranges (one byte per range quarter), next byte after LPS | after MPS << 8 } */
     u8  sigtab[35][16];                                     /* sig_coeff_flag context per scan position of a 4x4 group, by (size class, scan, neighbours, first group) */                         /* context byte after an MPS / LPS  [ref HEVCe.c:701-702] */
     u8  d4pos[16], d4idx[16];                               /* diagonal scan inside a 4x4 group: idx->(y<<2|x), (y<<2|x)->idx */
     u8  cgpos[3][64], cgidx[3][64];                         /* group order for 2x2 / 4x4 / 8x8 groups: idx->(gy<<3|gx), gy*ncg+gx->idx */
@@ -174,7 +179,6 @@ struct alignas(16) HvLds {
         HvTuInfo tinfo[HV_TL][4];
         u8  tdead[HV_TL];                                   /* abandoned: partial cost already above best_cost */
         int best_cost;                                      /* lowest cost of a COMPLETED candidate (pruning bound) */
-        int quota;                                          /* chunks a parent candidate advances per child phase */
         int split_inc, ml, ma;                              /* neighbour context read at the CU's entry [ref :1369-1373] */
     } lv[3];
     u8  shdr[HV_TL][HEVCE_TOKEN_SLOTS + 2];                 /* chunks per slot of the level being prepared (transient) */
@@ -191,6 +195,7 @@ struct alignas(16) HvLds {
     int   nxn_modes[4];
     /* control */
     int winner, split_sse;
+    int l0_active;                                          /* 8x8 candidates whose engines still run in this engine phase */
     unsigned long long prof[3][8];
     unsigned long long prof2[16];                           /* HEVCE_PROF: inside the NxN job (tu jobs, tokenise, engine, select) */
     int *trace;
@@ -290,26 +295,34 @@ static HD void hv_cod_carry(HvCod &c) {                                         
         }
     }
 }
-/* same state machine with the common case (one finished byte, no pending 0xff run) straight-line */
+/* same state machine for the lockstep engines: with dozens of candidates per wavefront SOME lane finishes a byte at nearly
+   every token, so a branch around this code is taken all the time and only adds its own cost.  The common case (at most
+   one finished byte, no pending run of 0xff bytes to flush) is therefore straight-line code executed for every token --
+   every assignment is a select on `need`; only the flush of a 0xff run, which is rare, stays a branch. */
 static HD void hv_cod_carry_fast(HvCod &c) {
-    if (c.nbits < 12) {
-        const int lead = (int)(c.low >> (24 - c.nbits));
-        c.nbits += 8;
-        c.low &= 0xffffffffu >> c.nbits;
-        if (c.nbytes > 1 && lead != 0xff) {                  /* rare: flush a run of buffered 0xff bytes */
-            const int carry = lead >> 8, fill = (0xff + carry) & 0xff;
-            hv_cod_out(c, c.bufbyte + carry);
-            c.bufbyte = lead & 0xff;
-            for (; c.nbytes > 1; c.nbytes--) hv_cod_out(c, fill);
-        } else {
-            const int isff = lead == 0xff, emit = !isff && c.nbytes > 0;
-            const int byte = (c.bufbyte + (lead >> 8)) & 0xff;
-            const int epb = emit && c.zeros >= 2 && byte <= 3;
-            c.nout += emit + epb;
-            c.zeros = emit ? (byte ? 0 : (epb ? 1 : c.zeros + 1)) : c.zeros;
-            c.nbytes = isff ? c.nbytes + 1 : 1;
-            c.bufbyte = isff ? c.bufbyte : (emit ? (lead & 0xff) : lead);     /* first byte ever: stored unmasked, as the reference does */
-        }
+    const int need = c.nbits < 12;
+    const int lead = (int)(c.low >> ((24 - c.nbits) & 31));     /* meaningful when need: shift 13..24 */
+    const int nb8 = c.nbits + 8;
+    const int rare = need & (c.nbytes > 1) & (lead != 0xff);     /* a run of buffered 0xff bytes must be flushed */
+    const int go = need & (rare ^ 1);
+    {
+        const int isff = lead == 0xff, emit = go & (isff ^ 1) & (c.nbytes > 0);
+        const int byte = (c.bufbyte + (lead >> 8)) & 0xff;
+        const int epb = emit & (c.zeros >= 2) & (byte <= 3);
+        c.nout += emit + epb;
+        c.zeros = emit ? (byte ? 0 : (epb ? 1 : c.zeros + 1)) : c.zeros;
+        c.nbytes = go ? (isff ? c.nbytes + 1 : 1) : c.nbytes;
+        c.bufbyte = (go & (isff ^ 1)) ? (emit ? (lead & 0xff) : lead) : c.bufbyte;   /* first byte ever: stored unmasked, as the reference does */
+        c.low = go ? (c.low & (0xffffffffu >> nb8)) : c.low;
+        c.nbits = go ? nb8 : c.nbits;
+    }
+    if (__builtin_expect(rare, 0)) {
+        c.nbits = nb8;
+        c.low &= 0xffffffffu >> nb8;
+        const int carry = lead >> 8, fill = (0xff + carry) & 0xff;
+        hv_cod_out(c, c.bufbyte + carry);
+        c.bufbyte = lead & 0xff;
+        for (; c.nbytes > 1; c.nbytes--) hv_cod_out(c, fill);
     }
 }
 /* context-coded bin; cx points at this trial's context byte  [ref :914-933] */
@@ -640,14 +653,20 @@ static HD int hv_chunk_get(const HvChunk &c, int i) {
    exceeds the cost of a candidate that has COMPLETED (or of the split alternative, known beforehand) it cannot be the
    arg-min, which is the LAST candidate of MINIMAL cost (ref :1440 adopts on >=).  Returns 1 when abandoned.
    [ref CABACputBin / CABACputBins :899-933] */
-/* one token through the coder: context-coded bin or bypass chunk, same straight-line code (table driven).
-   cp / cv = the token's context byte address and its (already fetched) value; returns the value written back */
-static HD int hv_engine_step(const HvLds &S, HvCod &c, u8 *cp, int cv, int tok) {
+/* one token through the coder: context-coded bin or bypass chunk, same straight-line code.
+   cv = the token's context byte, ct = S.ctab[cv] -- both fetched while the PREVIOUS token was processed, so that no
+   memory access sits on the range -> range dependency chain (the LPS range is a byte of ct picked by the range quarter,
+   its renormalisation shift a leading-zero count).  Returns the context byte to write back. */
+struct HvCt { unsigned lps4, nxt; };
+static HD int hv_engine_next_cv(int tok, int cv, const HvCt &ct) {
+    const int isb = (tok >> 15) & 1, islps = (((tok >> 14) & 1) ^ cv) & 1;
+    return isb ? cv : (int)((ct.nxt >> (islps ? 0 : 8)) & 0xff);
+}
+static HD void hv_engine_step(HvCod &c, int cv, const HvCt &ct, int tok) {
     const int isb = (tok >> 15) & 1;
     const int nb = (tok >> 8) & 15, bv = tok & 0xff;
-    const int e = S.lpsq[((cv & 0x7e) << 1) | ((c.range >> 6) & 3)];
-    const int nm = S.nxt_mps[cv], nl = S.nxt_lps[cv];
-    const int lps = e & 0xff, shl = e >> 8;
+    const int lps = (int)((ct.lps4 >> (((c.range >> 6) & 3) << 3)) & 0xff);
+    const int shl = hv_clz((unsigned)lps) - 23;                  /* lps in 6..240: 1..6 */
     const int islps = (((tok >> 14) & 1) ^ cv) & 1;
     const int rm = c.range - lps;
     const int shm = (rm < 256) ? 1 : 0;
@@ -658,80 +677,105 @@ static HD int hv_engine_step(const HvLds &S, HvCod &c, u8 *cp, int cv, int tok) 
     c.low = isb ? low_b : low_c;
     c.range = isb ? c.range : range_c;
     c.nbits -= isb ? nb : sh_c;
-    const int ncv = isb ? cv : (islps ? nl : nm);
-    *cp = (u8)ncv;
     hv_cod_carry_fast(c);
-    return ncv;
 }
 static HD u8 *hv_tok_ctx_ptr(u8 *cx, int tok) { return cx + ((tok & HV_TOK_BYP) ? (HEVCE_NCTXP - 1) * HV_TL : (tok & 0x1fff)); }   /* bypass: pad context */
 
+/* Token j of chunk pair (cur, nxt): j < 8 from cur, else from nxt. */
+static HD int hv_chunk_tok(const HvChunk &cur, const HvChunk &nxt, int j) {
+    const unsigned d = (j < 8) ? cur[(j & 7) >> 1] : nxt[(j & 7) >> 1];
+    return (int)((d >> ((j & 1) << 4)) & 0xffffu);
+}
+/* One chunk (8 tokens) through the coder, software-pipelined two tokens deep so that no LDS latency is exposed:
+   while token j goes through the coder registers (hv_engine_step, pure ALU), the context byte of token j+2 and the table
+   entry of token j+1 are in flight.  A = token j (context byte and table entry ready), B = token j+1 (raw context byte
+   read BEFORE token j's write-back: patched when both use the same context).  LDS executes in order, so a read issued
+   after a write sees it.  On return A / B describe tokens 8 and 9, i.e. the first two of `nxt`. */
+struct HvTokA { int tok, cv; u8 *cp; HvCt ct; };
+struct HvTokB { int tok, cvl; u8 *cp; };
+static HD void hv_engine_chunk(const HvLds &S, HvCod &c, u8 *cx, const HvChunk &cur, const HvChunk &nxt, HvTokA &A, HvTokB &B, int nvalid) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int ncv = hv_engine_next_cv(A.tok, A.cv, A.ct);
+        *A.cp = (u8)ncv;
+        const int cvb = (B.cp == A.cp) ? ncv : B.cvl;
+        const HvCt ctb = { S.ctab[cvb][0], S.ctab[cvb][1] };
+        int tc = hv_chunk_tok(cur, nxt, j + 2);
+        tc = (j + 2 < nvalid) ? tc : HV_TOK_NOP;
+        u8 *cpc = hv_tok_ctx_ptr(cx, tc);
+        const int cvlc = *cpc & 0x7f;
+        hv_engine_step(c, A.cv, A.ct, A.tok);
+        A.tok = B.tok; A.cv = cvb; A.cp = B.cp; A.ct = ctb;
+        B.tok = tc; B.cvl = cvlc; B.cp = cpc;
+    }
+}
+static HD void hv_engine_prime(const HvLds &S, u8 *cx, const HvChunk &first, HvTokA &A, HvTokB &B, int nvalid) {
+    A.tok = nvalid > 0 ? (int)(first[0] & 0xffffu) : HV_TOK_NOP;
+    A.cp = hv_tok_ctx_ptr(cx, A.tok);
+    A.cv = *A.cp & 0x7f;
+    A.ct.lps4 = S.ctab[A.cv][0]; A.ct.nxt = S.ctab[A.cv][1];
+    B.tok = nvalid > 1 ? (int)(first[0] >> 16) : HV_TOK_NOP;
+    B.cp = hv_tok_ctx_ptr(cx, B.tok);
+    B.cvl = *B.cp & 0x7f;
+}
+
+/* contiguous stream of n tokens at sp (16-byte chunks; the NxN sub-search's streams in LDS) */
 template <typename ChunkPtr>
-static HD int hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int i0, int i1, int q = 0, int sse = 0, int bits0 = 0, const int *best = nullptr) {
-    if (i0 >= i1) return 0;
-    int base = i0 & ~7;
-    HvChunk nxt = sp[base >> 3];
-    for (; base < i1; base += 8) {
+static HD void hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int n) {
+    if (n <= 0) return;
+    HvChunk nxt = sp[0];
+    HvTokA A; HvTokB B;
+    hv_engine_prime(S, cx, nxt, A, B, n);
+    for (int base = 0; base < n; base += 8) {
         const HvChunk cur = nxt;
         nxt = sp[(base >> 3) + 1];                                /* requested eight tokens ahead of its first use */
-        /* tokens outside [i0, i1) become no-ops; the context byte of token j+1 is fetched while token j is processed and
-           forwarded when both use the same context */
-        int tok = (base >= i0 && base < i1) ? (int)(cur[0] & 0xffffu) : HV_TOK_NOP;
-        u8 *cp = hv_tok_ctx_ptr(cx, tok);
-        int cv = *cp & 0x7f;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int in = base + j + 1;
-            int tn = HV_TOK_NOP;
-            if (j < 7) tn = (in >= i0 && in < i1) ? (int)((cur[(j + 1) >> 1] >> (((j + 1) & 1) << 4)) & 0xffffu) : HV_TOK_NOP;
-            u8 *cpn = hv_tok_ctx_ptr(cx, tn);
-            const int cvl = *cpn & 0x7f;
-            const int ncv = hv_engine_step(S, c, cp, cv, tok);
-            cv = (cpn == cp) ? ncv : cvl;
-            cp = cpn; tok = tn;
-        }
-        if (best && (base & 8) && hv_rdcost(q, sse, hv_cod_bits(c) - bits0) > hv_peek(best)) return 1;
+        hv_engine_chunk(S, c, cx, cur, nxt, A, B, n - base);
     }
-    return 0;
 }
 
 /* The same engine over a candidate's SLOTS in HBM: ls[0..nlist) lists its non-empty slots in coding order as
    (slot index | chunks << 8); (k, ci) = list entry and chunk inside that slot where work continues -- together with the
-   coder registers that is all the state, so a candidate can be advanced `budget` chunks at a time.  Slots are whole
-   chunks (padded with no-op tokens), so no token needs a range check.  Returns 1 when abandoned. */
+   coder registers that is all the state, so a candidate can be advanced a few chunks at a time.  Slots are whole chunks
+   (padded with no-op tokens), so no token needs a range check.  `dead` on entry / return: abandoned (see hv_engine).
+   shared == nullptr: run the candidate to its end.
+   shared != nullptr: a phase in which 8x8 candidates (notify = shared) run to their end and the candidates of the enclosing
+   CUs (notify == nullptr) ride along for as long as that takes: *shared counts the 8x8 engines still running in the whole
+   workgroup, and EVERY lane stays in the loop until it reaches zero; a lane that is done signals once and then idles.
+   The signal is ordinary loop-body code followed by further iterations, so it is issued when the lane finishes and not
+   when the slowest lane of its wavefront does -- the parents' lanes in that very wavefront are waiting for it. */
 static HD int hv_engine_slots(const HvLds &S, HvCod &c, u8 *cx, const HV_GLOBAL u16 *slots, const HV_LDSP u16 *ls, int nlist, int &k, int &ci,
-                              int budget, int q, int sse, int bits0, const int *best) {
+                              int dead, int *shared, int notify, int q, int sse, int bits0, int *best) {
     int e = ls[hv_min(k, nlist - 1)];
     int nch = e >> 8;
     const HV_GLOBAL HvChunk *ptr = (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HV_SLOT + HV_SLOT_TOK0) + ci;
     HvChunk nxt = *ptr;
-    int it = 0;
-    while (budget > 0 && k < nlist) {
-        const HvChunk cur = nxt;
-        ci++;                                                     /* where the chunk after this one lives; request it now */
-        const int adv = ci >= nch;
-        k += adv;
-        e = ls[hv_min(k, nlist - 1)];
-        ci = adv ? 0 : ci;
-        nch = adv ? (e >> 8) : nch;
-        ptr = adv ? (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HV_SLOT + HV_SLOT_TOK0) : ptr + 1;
-        nxt = *ptr;
-        int tok = (int)(cur[0] & 0xffffu);
-        u8 *cp = hv_tok_ctx_ptr(cx, tok);
-        int cv = *cp & 0x7f;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int tn = HV_TOK_NOP;
-            if (j < 7) tn = (int)((cur[(j + 1) >> 1] >> (((j + 1) & 1) << 4)) & 0xffffu);
-            u8 *cpn = hv_tok_ctx_ptr(cx, tn);
-            const int cvl = *cpn & 0x7f;
-            const int ncv = hv_engine_step(S, c, cp, cv, tok);
-            cv = (cpn == cp) ? ncv : cvl;
-            cp = cpn; tok = tn;
+    int it = 0, pub = 0;
+    HvTokA A; HvTokB B;
+    hv_engine_prime(S, cx, nxt, A, B, 8);
+    for (;;) {
+        const int done = dead || k >= nlist;
+        if (done && !pub) {                                       /* once, at the moment the lane finishes */
+            pub = 1;
+            if (!dead && best) hv_atomic_min(best, hv_rdcost(q, sse, hv_cod_bits(c) - bits0));   /* tightens everyone's pruning bound */
+            if (notify) hv_atomic_dec(shared);
         }
-        budget--; it++;
-        if (best && !(it & 1) && hv_rdcost(q, sse, hv_cod_bits(c) - bits0) > hv_peek(best)) return 1;
+        if (shared ? (hv_poll(shared) <= 0) : done) break;
+        if (!done) {
+            const HvChunk cur = nxt;
+            ci++;                                                 /* where the chunk after this one lives; request it now */
+            const int adv = ci >= nch;
+            k += adv;
+            e = ls[hv_min(k, nlist - 1)];
+            ci = adv ? 0 : ci;
+            nch = adv ? (e >> 8) : nch;
+            ptr = adv ? (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HV_SLOT + HV_SLOT_TOK0) : ptr + 1;
+            nxt = *ptr;
+            hv_engine_chunk(S, c, cx, cur, nxt, A, B, 16);
+            it++;
+            if (best && !(it & 1) && hv_rdcost(q, sse, hv_cod_bits(c) - bits0) > hv_peek(best)) dead = 1;
+        }
     }
-    return 0;
+    return dead;
 }
 
 /* --------------------------------------------------------------------------------------------- */
@@ -817,6 +861,13 @@ static HD int hv_smoothed(int n, int m) {
     return n == 8 ? d > 7 : n == 16 ? d > 1 : d > 0;
 }
 
+#ifdef HEVCE_PROF_TU
+#define HV_TUT(ph) do { if (N == HEVCE_PROF_TU && lane == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); HV_S.prof2[8 + (ph)] += n_ - tt_; tt_ = n_; } } while (0)
+#define HV_TUT0() unsigned long long tt_ = __builtin_amdgcn_s_memtime()
+#else
+#define HV_TUT(ph) do { } while (0)
+#define HV_TUT0() do { } while (0)
+#endif
 template <int N, typename LevP, typename RecP>
 static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
                             int ty, int tx,                         /* block origin, CTU-relative            */
@@ -837,6 +888,7 @@ static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
     u8 *pred = W.pred + slot * N * N;
     u8 *braw = W.bord + slot * 2 * BS, *bsm = braw + BS;         /* [0] corner, [1..2N] left, [1+2N..4N] above */
 
+    HV_TUT0();
     /* ---- reference samples  [ref HEVCe.c:196-257] ---- */
     {
         int corner;
@@ -879,6 +931,7 @@ static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
     for (int s = 1; s < N; s <<= 1) dcsum += hv_shfl_xor(dcsum, s);
     WAVE_SYNC();
 
+    HV_TUT(0);
     /* ---- prediction of column j  [ref HEVCe.c:262-381]; residual goes to scr, prediction to pred ---- */
     {
         const u8 *b = hv_smoothed(N, m) ? bsm : braw;
@@ -933,6 +986,7 @@ static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
         }
     }
 
+    HV_TUT(1);
     /* ---- forward transform, columns then rows  [ref HEVCe.c:497-516] ---- */
     int v[N];
     {
@@ -948,6 +1002,7 @@ static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
         }
     }
     WAVE_SYNC();
+    HV_TUT(2);
     /* ---- row pass + quantiser + dequantiser on row j  [ref HEVCe.c:540-615] ---- */
     const int kind = hv_scan_kind(N, m);
     int last = -1, nzmask_lo = 0, nzmask_hi = 0;
@@ -996,6 +1051,7 @@ static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
         nzmask_hi |= hv_shfl_xor(nzmask_hi, s);
     }
     WAVE_SYNC();
+    HV_TUT(3);
     /* ---- inverse transform, columns then rows ---- */
     {
 #pragma unroll
@@ -1009,6 +1065,7 @@ static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
         }
     }
     WAVE_SYNC();
+    HV_TUT(4);
     int sse = 0;
     {
 #pragma unroll
@@ -1028,6 +1085,7 @@ static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
     }
     for (int s = 1; s < N; s <<= 1) sse += hv_shfl_xor(sse, s);
     WAVE_SYNC();
+    HV_TUT(5);
     HvTuOut o;
     o.sse = sse; o.cbf = (last >= 0); o.last = last < 0 ? 0 : last;
     o.cgsig = ((u64)(unsigned)nzmask_hi << 32) | (unsigned)nzmask_lo;
@@ -1265,7 +1323,7 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
             hv_cg_load(S, g, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0), 1);
             const int nb = hv_cg_emit(S, wb, g, 0);
             HV_PROF2(S, 1);
-            hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), 0, na + nb);
+            hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb);
             cost = hv_rdcost(q, S.nxn_sse[lane], hv_cod_bits(c));
             idx = lane;
         }
@@ -1337,33 +1395,41 @@ static HD void hv_level_begin(HvLds &S, const HvCu cu) {
 }
 
 /* TU-job phase of the 8x8 CU number m (0..3) of the 16x16 CU number k16 (0..3).  Wavefront 0 walks the NxN chain, the
-   longest job by far; the other seven run the 8x8 CU's eight block jobs AND, in the time wavefront 0 leaves them, the
+   longest job by far (wavefront 4, on the same SIMD, stays idle); the other six run the 8x8 CU's eight block jobs AND, in the time wavefront 0 leaves them, the
    jobs of the enclosing CUs, which only depend on samples outside those CUs: all 14 jobs of the 16x16 CU during its first
-   child (m == 0), the 27 jobs of the 32x32 CU during children 1..3 of the first 16x16 CU.  The schedule is static and
+   child (m == 0), the 27 jobs of the 32x32 CU during children 1..3 of the first and 1..2 of the second 16x16 CU.  The schedule is static and
    wave-uniform (SGPRs): no lane-dependent control flow may surround the calls, the jobs use wave-level shuffles. */
+#ifdef HEVCE_PROF_JOBS
+#define HV_JOBT(slot, call) do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); call; if (lane == 0) S.prof2[slot] += __builtin_amdgcn_s_memtime() - t0_; } while (0)
+#else
+#define HV_JOBT(slot, call) call
+#endif
 static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
     const int wv = hv_uni(wave);
     k16 = hv_uni(k16); m = hv_uni(m);
     HV_GLOBAL u8 *s0 = hv_level_scratch(im, 0), *s1 = hv_level_scratch(im, 1), *s2 = hv_level_scratch(im, 2);
     if (wv == 0) { hv_job_nxn(wave, lane, q, c8); return; }
-    const int w1 = wv - 1;                                       /* 0..6 */
-    /* 8x8: jobs 0..2 = TU-split chains (16 modes each), 3..7 = single TUs (8 modes each) */
-    if (w1 < 3) hv_job_chain<4>(wave, lane, q, c8, w1, (HvGLev)s0, (HvGRec)(s0 + HV_TL * 1024 * 2));
-    else hv_job_single<8>(wave, lane, q, c8, w1 - 3, (HvGLev)s0, (HvGRec)(s0 + HV_TL * 1024 * 2));
-    if (w1 == 6) hv_job_single<8>(wave, lane, q, c8, 4, (HvGLev)s0, (HvGRec)(s0 + HV_TL * 1024 * 2));
+    if (wv == 4) return;                                         /* shares its SIMD with wavefront 0: stays idle */
+    const int w1 = wv < 4 ? wv - 1 : wv - 2;                     /* work slot 0..5 */
+    HvGLev l0 = (HvGLev)s0, l1 = (HvGLev)s1, l2 = (HvGLev)s2;
+    HvGRec r0 = (HvGRec)(s0 + HV_TL * 1024 * 2), r1 = (HvGRec)(s1 + HV_TL * 1024 * 2), r2 = (HvGRec)(s2 + HV_TL * 1024 * 2);
+    /* 8x8: 3 TU-split chains (16 modes each) on slots 0..2, 5 single TUs (8 modes each) on slots 3..5 */
+    if (w1 < 3) HV_JOBT(8, hv_job_chain<4>(wave, lane, q, c8, w1, l0, r0));
+    else {
+        HV_JOBT(9, hv_job_single<8>(wave, lane, q, c8, 2 * (w1 - 3), l0, r0));
+        if (w1 < 5) HV_JOBT(9, hv_job_single<8>(wave, lane, q, c8, 2 * (w1 - 3) + 1, l0, r0));
+    }
     if (m == 0) {
-        /* 16x16: 5 chains (8 modes each) on wavefronts 1..5, 9 single TUs (4 modes each) */
-        if (w1 < 5) hv_job_chain<8>(wave, lane, q, c16, w1, (HvGLev)s1, (HvGRec)(s1 + HV_TL * 1024 * 2));
-        else { hv_job_single<16>(wave, lane, q, c16, w1 - 5, (HvGLev)s1, (HvGRec)(s1 + HV_TL * 1024 * 2));
-               hv_job_single<16>(wave, lane, q, c16, w1 - 3, (HvGLev)s1, (HvGRec)(s1 + HV_TL * 1024 * 2)); }
-        if (w1 < 5) hv_job_single<16>(wave, lane, q, c16, 4 + w1, (HvGLev)s1, (HvGRec)(s1 + HV_TL * 1024 * 2));
-    } else if (k16 == 0) {
-        /* 32x32: 9 chains (4 modes each) then 18 single TUs (2 modes each) in pairs: 18 work slots over 3 x 7 */
-        const int idx = (m - 1) * 7 + w1;
-        if (idx < 9) hv_job_chain<16>(wave, lane, q, c32, idx, (HvGLev)s2, (HvGRec)(s2 + HV_TL * 1024 * 2));
-        else if (idx < 18) { hv_job_single<32>(wave, lane, q, c32, 2 * (idx - 9), (HvGLev)s2, (HvGRec)(s2 + HV_TL * 1024 * 2));
-                             hv_job_single<32>(wave, lane, q, c32, 2 * (idx - 9) + 1, (HvGLev)s2, (HvGRec)(s2 + HV_TL * 1024 * 2)); }
+        /* 16x16: 5 chains (8 modes each) on slots 0..4, 9 single TUs (4 modes each): one each on slots 0..4, four on slot 5 */
+        if (w1 < 5) { HV_JOBT(10, hv_job_chain<8>(wave, lane, q, c16, w1, l1, r1)); HV_JOBT(11, hv_job_single<16>(wave, lane, q, c16, w1, l1, r1)); }
+        else for (int j = 5; j < 9; j++) HV_JOBT(11, hv_job_single<16>(wave, lane, q, c16, j, l1, r1));
+    } else if (k16 < 2 && !(k16 == 1 && m == 3)) {
+        /* 32x32: 9 chains (4 modes each, ~180 k cycles) and 18 single TUs (2 modes each, ~160 k): one per work slot in the
+           five phases (k16, m) = (0,1) (0,2) (0,3) (1,1) (1,2); a second one would outlast the NxN chain (~270 k) */
+        const int idx = (k16 * 3 + m - 1) * 6 + w1;
+        if (idx < 9) HV_JOBT(12, hv_job_chain<16>(wave, lane, q, c32, idx, l2, r2));
+        else if (idx < 27) HV_JOBT(13, hv_job_single<32>(wave, lane, q, c32, idx - 9, l2, r2));
     }
 }
 
@@ -1431,7 +1497,7 @@ static HD void hv_bin_cu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GL
 }
 
 /* candidates of one CU after their TU jobs: engine state from the entry snapshot, binarisation, linking */
-static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu cu, int phases) {
+static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu cu) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, n = cu.n;
     HvLds::Level &L = S.lv[cu.lvl];
     HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
@@ -1474,34 +1540,40 @@ static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu
     for (int t = tid; t < ntrials; t += HV_NTHREADS) {
         const int nslots = hv_trial_slots(n, t);
         HV_LDSP u16 *ls = hv_slist(S, cu.lvl, t);
-        int k = 0, tot = 0;
+        int k = 0;
         for (int f = 0; f < nslots; f++) {
             const int ch = S.shdr[t][f];
             ls[k] = (u16)(f | (ch << 8));
-            k += (ch != 0); tot += ch;
+            k += (ch != 0);
         }
         L.tlen[t] = k; L.tpos[t] = 0;
-        L.tcost[t] = tot;                                        /* until the candidate completes: its length in chunks */
     }
     BLOCK_SYNC();
     HV_PROF3L(2);
-    if (tid == 0) {                                              /* slice size of a parent's candidates: done by its last child */
-        int mx_len = 0;
-        for (int t = 0; t < ntrials; t++) mx_len = hv_max(mx_len, L.tcost[t]);
-        L.quota = (n == 8) ? 0x7fffffff : ((mx_len + phases - 1) / phases + 2);
-    }
+    if (tid == 0 && n == 8) S.l0_active = 71;                   /* see hv_engine_phase */
     BLOCK_SYNC();
     HV_PROF3L(3);
     HV_PROF(S, cu.lvl, 5);
 }
 
-/* lanes 0..8 of every wavefront: 8x8 candidates; 9..17: 16x16; 18..26: 32x32 (candidate = lane' * 8 + wave).
+/* Engines run on HV_ENG_WAVES wavefronts only -- one per SIMD, so that each issues at full rate (the loop is a single
+   dependent instruction stream; two engine wavefronts on one SIMD would take turns).  Lanes 0..17 of such a wavefront:
+   8x8 candidates; 18..35: 16x16; 36..53: 32x32 (candidate = lane' * 4 + wave).
    mask: bit l set = level l takes part; `finish` lifts the quota (used when a parent is decided). */
+#ifndef HV_ENG_WAVES
+#define HV_ENG_WAVES 4
+#endif
+#ifndef HV_ENG_WAVE_OF
+#define HV_ENG_WAVE_OF(w) (w)                                 /* engine wavefront index -> hardware wavefront */
+#endif
 static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int finish) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
     HV_PROF_T0();
-    const int lvl = lane / 9, t = (lane % 9) * HV_NWAVES + wave;
-    if (lvl < 3 && ((mask >> lvl) & 1)) {
+    const int per = HV_TL / HV_ENG_WAVES;
+    int ew = -1;
+    for (int i = 0; i < HV_ENG_WAVES; i++) if (HV_ENG_WAVE_OF(i) == wave) ew = i;
+    const int lvl = lane / per, t = (lane % per) * HV_ENG_WAVES + ew;
+    if (ew >= 0 && lvl < 3 && ((mask >> lvl) & 1)) {
         HvLds::Level &L = S.lv[lvl];
         const int ntrials = (lvl == 0) ? 71 : 70;
         if (t < ntrials && L.tpos[t] >= 0) {
@@ -1510,10 +1582,10 @@ static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int
             HvCod c;
             hv_cod_load(c, L.tregs[t]);
             const int bits0 = hv_regs_bits(S.ent[lvl]);
-            const int budget = (finish || lvl == 0) ? 0x7fffffff : L.quota;
             const HV_GLOBAL u16 *slots = (const HV_GLOBAL u16 *)(hv_level_scratch(im, lvl) + HV_TL * 1024 * 3) + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT;
             int dead = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0) > hv_peek(&L.best_cost);
-            if (!dead) dead = hv_engine_slots(S, c, &L.tctx[0][t], slots, hv_slist(S, lvl, t), nlist, k, ci, budget, q, L.tsse[t], bits0, &L.best_cost);
+            dead = hv_engine_slots(S, c, &L.tctx[0][t], slots, hv_slist(S, lvl, t), nlist, k, ci, dead, finish ? nullptr : &S.l0_active,
+                                   !finish && lvl == 0, q, L.tsse[t], bits0, &L.best_cost);
             hv_cod_store(L.tregs[t], c);
             if (dead) { L.tdead[t] = 1; L.tcost[t] = HV_I32MAX; L.tpos[t] = -1; }
             else if (k >= nlist) {
@@ -1599,14 +1671,11 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, H
 /* --------------------------------------------------------------------------------------------- */
 static HD void hv_init_tables(HvLds &S, int q, int tid) {
     if (tid < 64) { S.lps4[tid] = hv_lps4[tid]; S.lpsnext[tid] = hv_lpsnext[tid]; }
-    if (tid < 256) {
-        const int lps = (int)((hv_lps4[tid >> 2] >> ((tid & 3) << 3)) & 0xff);
-        S.lpsq[tid] = (u16)(lps | (((lps < 8) ? 6 : hv_clz((unsigned)(lps >> 3)) - 26) << 8));
-    }
     if (tid >= 256 && tid < 384) {
         const int cv = tid - 256, st = cv >> 1, mps = cv & 1;
-        S.nxt_mps[cv] = (u8)(st < 62 ? cv + 2 : cv);
-        S.nxt_lps[cv] = (u8)(st == 0 ? (mps ^ 1) : ((hv_lpsnext[st] << 1) | mps));
+        const int nm = st < 62 ? cv + 2 : cv, nl = st == 0 ? (mps ^ 1) : ((hv_lpsnext[st] << 1) | mps);
+        S.ctab[cv][0] = hv_lps4[st];
+        S.ctab[cv][1] = (unsigned)(nl | (nm << 8));
     }
     if (tid == 64) {
         /* up-right diagonal order inside a 4x4 group and over 2x2 / 4x4 / 8x8 groups  [ref :1130-1132] */
@@ -1727,10 +1796,10 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     hv_jobs_phase(S, im, cu, c16, c32, k, m);
                     BLOCK_SYNC();                                /* the NxN job borrows the 8x8 level's context columns */
                     HV_PROF(S, 0, 0);
-                    hv_prepare_streams(S, im, cu, 1);
-                    if (m == 0) hv_prepare_streams(S, im, c16, 4);
-                    if (k == 0 && m == 3) hv_prepare_streams(S, im, c32, 13);     /* its jobs ran during m = 1..3 */
-                    hv_engine_phase(S, im, (k == 0 && m < 3) ? 3 : 7, 0);
+                    hv_prepare_streams(S, im, cu);
+                    if (m == 0) hv_prepare_streams(S, im, c16);
+                    if (k == 1 && m == 2) hv_prepare_streams(S, im, c32);     /* its jobs ran in five phases up to this one */
+                    hv_engine_phase(S, im, (k == 0 || (k == 1 && m < 2)) ? 3 : 7, 0);
                 }
                 hv_decide_cu(S, im, cu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr);
             }

@@ -56,6 +56,7 @@ void emu_wave_sync(void) {
     wave_wait[emu_cur >> 6]++;
     yield_to_sched();
 }
+void emu_yield(void) { yield_to_sched(); }                  /* stays runnable */
 void emu_block_sync(void) {
     fib[emu_cur].st = WAIT_BLOCK;
     block_wait++;
