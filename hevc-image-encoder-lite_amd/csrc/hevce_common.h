@@ -66,6 +66,7 @@ typedef struct HevceImageDesc {
 #define HEVCE_TRIALS        72                               /* 35 + 35 + 1 (+1 pad) trial slots */
 #define HEVCE_TOKEN_SLOT_WORDS 128                           /* 16-bit words per bin-token slot */
 #define HEVCE_TOKEN_SLOTS      70                            /* slots per trial: CU header + block headers + 4x4 groups */
-#define HEVCE_SCRATCH_LEVEL_BYTES (HEVCE_TRIALS * 1024 * 3 + HEVCE_TRIALS * HEVCE_TOKEN_SLOTS * HEVCE_TOKEN_SLOT_WORDS * 2)
+#define HEVCE_SINK_WORDS       8192                          /* finished-byte records per trial between two replays (a 32x32 CU: < 6200 bytes in all) */
+#define HEVCE_SCRATCH_LEVEL_BYTES (HEVCE_TRIALS * 1024 * 3 + HEVCE_TRIALS * HEVCE_TOKEN_SLOTS * HEVCE_TOKEN_SLOT_WORDS * 2 + HEVCE_TRIALS * HEVCE_SINK_WORDS * 2)
 #define HEVCE_SCRATCH_BYTES (3 * HEVCE_SCRATCH_LEVEL_BYTES)   /* one set per CU level: 8x8, 16x16, 32x32 candidates coexist */
                                                              /* int16 levels + u8 reconstruction + bin tokens per trial */

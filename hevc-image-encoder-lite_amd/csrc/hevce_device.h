@@ -74,11 +74,7 @@ static HD int  hv_clzll(unsigned long long v) { return __clzll((long long)v); }
 #define HV_PROF_T0()  unsigned long long pt_ = __builtin_amdgcn_s_memtime()
 #define HV_PROF2_T0() unsigned long long p2_ = __builtin_amdgcn_s_memtime()
 #define HV_PROF3(S, ph) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof2[ph] += n_ - pt_; pt_ = n_; } } while (0)
-#ifdef HEVCE_PROF_JOBS
-#define HV_PROF3L(k) do { if (cu.lvl == 0) HV_PROF3(S, 4 + (k)); } while (0)
-#else
 #define HV_PROF3L(k) HV_PROF3(S, 4 + 4 * cu.lvl + (k))
-#endif
 #define HV_PROF2(S, ph) do { if ((hv_tid() & 63) == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof2[ph] += n_ - p2_; p2_ = n_; } } while (0)
 #define HV_PROF(S, lvl, ph) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof[lvl][ph] += n_ - pt_; pt_ = n_; } } while (0)
 #else
@@ -184,8 +180,8 @@ struct alignas(16) HvLds {
     u8  shdr[HV_TL][HEVCE_TOKEN_SLOTS + 2];                 /* chunks per slot of the level being prepared (transient) */
     u16 slist0[HV_TL][10], slist1[HV_TL][22], slist2[HV_TL][70];   /* per level and candidate: non-empty slots, slot | chunks << 8 */
     /* NxN sub-search */
-    short nxn_lev[35][16];
-    u8    nxn_rec[35][16];
+    alignas(16) short nxn_lev[35][16];                      /* 16-byte rows: written / read as vectors */
+    alignas(16) u8    nxn_rec[35][16];
     int   nxn_sse[35], nxn_last[35], nxn_sig[35];
     short nxn_bestlev[4][16];
     alignas(16) u16 nxn_tok[35][144];                                 /* per candidate: its token stream (header + one group), 16-byte rows */
@@ -197,12 +193,14 @@ struct alignas(16) HvLds {
     int winner, split_sse;
     int l0_active;                                          /* 8x8 candidates whose engines still run in this engine phase */
     unsigned long long prof[3][8];
-    unsigned long long prof2[16];                           /* HEVCE_PROF: inside the NxN job (tu jobs, tokenise, engine, select) */
+    unsigned long long prof2[32];                           /* HEVCE_PROF: inside the NxN job (tu jobs, tokenise, engine, select) */
     int *trace;
     HvWaveScr ws[HV_NWAVES];
 };
 
-struct HvCod { int range; unsigned low; int nbits, nbytes, bufbyte, zeros, nout; };
+typedef unsigned HvChunk __attribute__((vector_size(16), may_alias));   /* 16 bytes moved as one dwordx4: eight 16-bit tokens / records, packed levels, samples */
+struct HvCod { int range; unsigned low; int nbits, nbytes, bufbyte, zeros, nout;
+               int nev, zf; };   /* lockstep engines: finished bytes recorded but not yet accounted (hv_cod_replay), "a zero byte or a carry may be among them" */
 
 /* The workgroup's LDS image.  The large routines below are separate (__noinline__) functions: they bind to this
    symbol directly instead of taking the image by reference, so that every access stays an LDS (ds_*) access. */
@@ -264,12 +262,15 @@ static HD void hv_scan_in(const HvLds &S, int kind, int ii, int &iy, int &ix) {
 /* --------------------------------------------------------------------------------------------- */
 static HD void hv_cod_load(HvCod &c, const HevceCoderRegs &r) {
     c.range = r.range; c.low = r.low; c.nbits = r.nbits; c.nbytes = r.nbytes; c.bufbyte = r.bufbyte; c.zeros = r.zeros; c.nout = r.nout;
+    c.nev = 0; c.zf = 0;
 }
 static HD void hv_cod_store(HevceCoderRegs &r, const HvCod &c) {
     r.range = c.range; r.low = c.low; r.nbits = c.nbits; r.nbytes = c.nbytes; r.bufbyte = c.bufbyte; r.zeros = c.zeros; r.nout = c.nout; r.pad = 0;
 }
-static HD void hv_cod_fresh(HvCod &c) { c.range = 510; c.low = 0; c.nbits = 23; c.nbytes = 0; c.bufbyte = 0xff; c.zeros = 0; c.nout = 0; }
-static HD int  hv_cod_bits(const HvCod &c) { return 8 * (c.nout + c.nbytes) + 23 - c.nbits; }            /* [ref :835-837] */
+static HD void hv_cod_fresh(HvCod &c) { c.range = 510; c.low = 0; c.nbits = 23; c.nbytes = 0; c.bufbyte = 0xff; c.zeros = 0; c.nout = 0; c.nev = 0; c.zf = 0; }
+/* bits so far  [ref :835-837].  With recorded-but-unaccounted bytes (nev > 0) this is a LOWER bound: the emulation-
+   prevention bytes among them, which the reference counts, are only known after hv_cod_replay; it is exact when !zf. */
+static HD int  hv_cod_bits(const HvCod &c) { return 8 * (c.nout + c.nbytes + c.nev) + 23 - c.nbits; }
 static HD int  hv_regs_bits(const HevceCoderRegs &c) { return 8 * (c.nout + c.nbytes) + 23 - c.nbits; }
 
 static HD void hv_cod_out(HvCod &c, int byte) {                                                            /* [ref :821-832] */
@@ -295,16 +296,32 @@ static HD void hv_cod_carry(HvCod &c) {                                         
         }
     }
 }
-/* same state machine for the lockstep engines: with dozens of candidates per wavefront SOME lane finishes a byte at nearly
-   every token, so a branch around this code is taken all the time and only adds its own cost.  The common case (at most
-   one finished byte, no pending run of 0xff bytes to flush) is therefore straight-line code executed for every token --
-   every assignment is a select on `need`; only the flush of a 0xff run, which is rare, stays a branch. */
-static HD void hv_cod_carry_fast(HvCod &c) {
+/* The lockstep engines split that state machine in two.  Per token (hv_cod_carry_rec) a finished byte is only RECORDED:
+   its 9-bit value (carry + byte) goes to a per-candidate sink and the count goes up -- a handful of instructions, where
+   the full byte bookkeeping (pending byte, runs of 0xff, emulation prevention) costs as much as the arithmetic itself
+   and, with dozens of candidates per wavefront, would be executed at every token.  hv_cod_replay() then runs the exact
+   bookkeeping once per recorded byte, i.e. for about one token in ten.
+   Start of a span: hv_cod_span(); zf stays 0 as long as no zero byte can have been emitted and no carry occurred -- then no
+   emulation-prevention byte can have been inserted and hv_cod_bits() is exact even before the replay. */
+static HD void hv_cod_span(HvCod &c) {
+    c.nev = 0;
+    c.zf = (c.zeros > 0) | ((c.bufbyte & 0xff) == 0) | ((c.bufbyte & 0xff) == 0xff) | (c.nbytes > 1);
+}
+template <typename SinkP> static HD void hv_cod_carry_rec(HvCod &c, SinkP sink) {
     const int need = c.nbits < 12;
-    const int lead = (int)(c.low >> ((24 - c.nbits) & 31));     /* meaningful when need: shift 13..24 */
+    const unsigned lead = c.low >> ((24 - c.nbits) & 31);       /* meaningful when need: shift 13..24 */
+    if (need) sink[c.nev] = (u16)lead;
     const int nb8 = c.nbits + 8;
-    const int rare = need & (c.nbytes > 1) & (lead != 0xff);     /* a run of buffered 0xff bytes must be flushed */
-    const int go = need & (rare ^ 1);
+    c.low = need ? (c.low & (0xffffffffu >> nb8)) : c.low;
+    c.nbits = need ? nb8 : c.nbits;
+    c.zf |= need & ((((lead & 0xff) == 0) | ((lead >> 8) != 0)) ? 1 : 0);
+    c.nev += need;
+}
+/* exact bookkeeping of one finished byte (`on` = there is one): hv_cod_carry without the register part; the common case
+   straight-line, the flush of a run of 0xff bytes a (rare) branch */
+static HD void hv_cod_byte(HvCod &c, int lead, int on) {
+    const int rare = on & (c.nbytes > 1) & (lead != 0xff);
+    const int go = on & (rare ^ 1);
     {
         const int isff = lead == 0xff, emit = go & (isff ^ 1) & (c.nbytes > 0);
         const int byte = (c.bufbyte + (lead >> 8)) & 0xff;
@@ -313,16 +330,21 @@ static HD void hv_cod_carry_fast(HvCod &c) {
         c.zeros = emit ? (byte ? 0 : (epb ? 1 : c.zeros + 1)) : c.zeros;
         c.nbytes = go ? (isff ? c.nbytes + 1 : 1) : c.nbytes;
         c.bufbyte = (go & (isff ^ 1)) ? (emit ? (lead & 0xff) : lead) : c.bufbyte;   /* first byte ever: stored unmasked, as the reference does */
-        c.low = go ? (c.low & (0xffffffffu >> nb8)) : c.low;
-        c.nbits = go ? nb8 : c.nbits;
     }
     if (__builtin_expect(rare, 0)) {
-        c.nbits = nb8;
-        c.low &= 0xffffffffu >> nb8;
         const int carry = lead >> 8, fill = (0xff + carry) & 0xff;
         hv_cod_out(c, c.bufbyte + carry);
         c.bufbyte = lead & 0xff;
         for (; c.nbytes > 1; c.nbytes--) hv_cod_out(c, fill);
+    }
+}
+template <typename ChunkP> static HD void hv_cod_replay(HvCod &c, ChunkP sink8) {     /* sink as 16-byte chunks of eight records */
+    const int n = c.nev;
+    c.nev = 0; c.zf = 0;
+    for (int base = 0; base < n; base += 8) {
+        const HvChunk ch = sink8[base >> 3];
+#pragma unroll
+        for (int j = 0; j < 8; j++) hv_cod_byte(c, (int)((ch[j >> 1] >> ((j & 1) << 4)) & 0xffffu), base + j < n);
     }
 }
 /* context-coded bin; cx points at this trial's context byte  [ref :914-933] */
@@ -383,7 +405,6 @@ static HD void hv_terminate(HvCod &c, int bin) {                                
 #define HV_TOK_NOP     HV_TOK_BYP
 #define HV_CT(idx, bin) (((idx) * HV_TL) | ((bin) ? 0x4000 : 0))   /* context-coded bin */
 
-typedef unsigned HvChunk __attribute__((vector_size(16)));   /* eight 16-bit tokens, loaded as one dwordx4 */
 template <typename P> struct HvTokW { P p; int n; };
 #define HV_SLOT_TOK0 8                      /* tokens start 16 bytes into the slot so that chunks of 8 load as one dwordx4 */
 
@@ -662,7 +683,7 @@ static HD int hv_engine_next_cv(int tok, int cv, const HvCt &ct) {
     const int isb = (tok >> 15) & 1, islps = (((tok >> 14) & 1) ^ cv) & 1;
     return isb ? cv : (int)((ct.nxt >> (islps ? 0 : 8)) & 0xff);
 }
-static HD void hv_engine_step(HvCod &c, int cv, const HvCt &ct, int tok) {
+template <typename SinkP> static HD void hv_engine_step(HvCod &c, int cv, const HvCt &ct, int tok, SinkP sink) {
     const int isb = (tok >> 15) & 1;
     const int nb = (tok >> 8) & 15, bv = tok & 0xff;
     const int lps = (int)((ct.lps4 >> (((c.range >> 6) & 3) << 3)) & 0xff);
@@ -677,7 +698,7 @@ static HD void hv_engine_step(HvCod &c, int cv, const HvCt &ct, int tok) {
     c.low = isb ? low_b : low_c;
     c.range = isb ? c.range : range_c;
     c.nbits -= isb ? nb : sh_c;
-    hv_cod_carry_fast(c);
+    hv_cod_carry_rec(c, sink);
 }
 static HD u8 *hv_tok_ctx_ptr(u8 *cx, int tok) { return cx + ((tok & HV_TOK_BYP) ? (HEVCE_NCTXP - 1) * HV_TL : (tok & 0x1fff)); }   /* bypass: pad context */
 
@@ -693,7 +714,7 @@ static HD int hv_chunk_tok(const HvChunk &cur, const HvChunk &nxt, int j) {
    after a write sees it.  On return A / B describe tokens 8 and 9, i.e. the first two of `nxt`. */
 struct HvTokA { int tok, cv; u8 *cp; HvCt ct; };
 struct HvTokB { int tok, cvl; u8 *cp; };
-static HD void hv_engine_chunk(const HvLds &S, HvCod &c, u8 *cx, const HvChunk &cur, const HvChunk &nxt, HvTokA &A, HvTokB &B, int nvalid) {
+template <typename SinkP> static HD void hv_engine_chunk(const HvLds &S, HvCod &c, u8 *cx, const HvChunk &cur, const HvChunk &nxt, HvTokA &A, HvTokB &B, int nvalid, SinkP sink) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int ncv = hv_engine_next_cv(A.tok, A.cv, A.ct);
@@ -704,7 +725,7 @@ static HD void hv_engine_chunk(const HvLds &S, HvCod &c, u8 *cx, const HvChunk &
         tc = (j + 2 < nvalid) ? tc : HV_TOK_NOP;
         u8 *cpc = hv_tok_ctx_ptr(cx, tc);
         const int cvlc = *cpc & 0x7f;
-        hv_engine_step(c, A.cv, A.ct, A.tok);
+        hv_engine_step(c, A.cv, A.ct, A.tok, sink);
         A.tok = B.tok; A.cv = cvb; A.cp = B.cp; A.ct = ctb;
         B.tok = tc; B.cvl = cvlc; B.cp = cpc;
     }
@@ -720,8 +741,8 @@ static HD void hv_engine_prime(const HvLds &S, u8 *cx, const HvChunk &first, HvT
 }
 
 /* contiguous stream of n tokens at sp (16-byte chunks; the NxN sub-search's streams in LDS) */
-template <typename ChunkPtr>
-static HD void hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int n) {
+template <typename ChunkPtr, typename SinkP>
+static HD void hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int n, SinkP sink) {
     if (n <= 0) return;
     HvChunk nxt = sp[0];
     HvTokA A; HvTokB B;
@@ -729,7 +750,7 @@ static HD void hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int n) {
     for (int base = 0; base < n; base += 8) {
         const HvChunk cur = nxt;
         nxt = sp[(base >> 3) + 1];                                /* requested eight tokens ahead of its first use */
-        hv_engine_chunk(S, c, cx, cur, nxt, A, B, n - base);
+        hv_engine_chunk(S, c, cx, cur, nxt, A, B, n - base, sink);
     }
 }
 
@@ -744,7 +765,7 @@ static HD void hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int n) {
    The signal is ordinary loop-body code followed by further iterations, so it is issued when the lane finishes and not
    when the slowest lane of its wavefront does -- the parents' lanes in that very wavefront are waiting for it. */
 static HD int hv_engine_slots(const HvLds &S, HvCod &c, u8 *cx, const HV_GLOBAL u16 *slots, const HV_LDSP u16 *ls, int nlist, int &k, int &ci,
-                              int dead, int *shared, int notify, int q, int sse, int bits0, int *best) {
+                              int dead, int *shared, int notify, int q, int sse, int bits0, int *best, HV_GLOBAL u16 *sink) {
     int e = ls[hv_min(k, nlist - 1)];
     int nch = e >> 8;
     const HV_GLOBAL HvChunk *ptr = (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HV_SLOT + HV_SLOT_TOK0) + ci;
@@ -756,7 +777,7 @@ static HD int hv_engine_slots(const HvLds &S, HvCod &c, u8 *cx, const HV_GLOBAL 
         const int done = dead || k >= nlist;
         if (done && !pub) {                                       /* once, at the moment the lane finishes */
             pub = 1;
-            if (!dead && best) hv_atomic_min(best, hv_rdcost(q, sse, hv_cod_bits(c) - bits0));   /* tightens everyone's pruning bound */
+            if (!dead && best && !c.zf) hv_atomic_min(best, hv_rdcost(q, sse, hv_cod_bits(c) - bits0));   /* exact (see hv_cod_span): tightens everyone's pruning bound */
             if (notify) hv_atomic_dec(shared);
         }
         if (shared ? (hv_poll(shared) <= 0) : done) break;
@@ -770,7 +791,7 @@ static HD int hv_engine_slots(const HvLds &S, HvCod &c, u8 *cx, const HV_GLOBAL 
             nch = adv ? (e >> 8) : nch;
             ptr = adv ? (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HV_SLOT + HV_SLOT_TOK0) : ptr + 1;
             nxt = *ptr;
-            hv_engine_chunk(S, c, cx, cur, nxt, A, B, 16);
+            hv_engine_chunk(S, c, cx, cur, nxt, A, B, 16, sink);
             it++;
             if (best && !(it & 1) && hv_rdcost(q, sse, hv_cod_bits(c) - bits0) > hv_peek(best)) dead = 1;
         }
@@ -862,7 +883,7 @@ static HD int hv_smoothed(int n, int m) {
 }
 
 #ifdef HEVCE_PROF_TU
-#define HV_TUT(ph) do { if (N == HEVCE_PROF_TU && lane == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); HV_S.prof2[8 + (ph)] += n_ - tt_; tt_ = n_; } } while (0)
+#define HV_TUT(ph) do { if (N == HEVCE_PROF_TU && lane == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); HV_S.prof2[16 + (ph)] += n_ - tt_; tt_ = n_; } } while (0)
 #define HV_TUT0() unsigned long long tt_ = __builtin_amdgcn_s_memtime()
 #else
 #define HV_TUT(ph) do { } while (0)
@@ -1152,7 +1173,15 @@ static HDN void hv_job_chain(int wave, int lane, int q, HvCu cu, int grp, HvGLev
    b = raw reference samples (corner, left[8], above[8]); 4x4 blocks never use the smoothed ones  [ref :274-275].
    Writes levels in scan order to lev_dst[16], the reconstruction (raster) to rec_dst[16]; returns SSE.
    [ref :1508-1518 = predict / residual / DST / RDOQ / dequant / inverse DST / reconstruct] */
+#ifdef HEVCE_PROF_NXN
+#define HV_NXT(ph) do { if ((hv_tid() & 63) == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); HV_S.prof2[16 + (ph)] += n_ - nt_; nt_ = n_; } } while (0)
+#define HV_NXT0() unsigned long long nt_ = __builtin_amdgcn_s_memtime()
+#else
+#define HV_NXT(ph) do { } while (0)
+#define HV_NXT0() do { } while (0)
+#endif
 static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int ty, int tx, int m, HV_LDSP short *lev_dst, HV_LDSP u8 *rec_dst, int &last_out) {
+    HV_NXT0();
     const u8 *l = b + 1, *a = b + 9;
     const int c = b[0];
     int p[16];
@@ -1208,6 +1237,7 @@ static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int 
             }
         }
     }
+    HV_NXT(0);
     int r[16], t[16];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -1231,16 +1261,32 @@ static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int 
             lv[i * 4 + j] = coef < 0 ? -mag : mag;
             sum += hv_min(d, thr);
         }
+    HV_NXT(1);
+    /* levels in scan order: the three 4x4 orders are compile-time permutations of the raster positions, picked per lane by
+       selects (no table reads, no divergent paths); two 16-byte LDS stores instead of sixteen scattered ones */
     const int kind = hv_scan_kind(4, m);
-    int last = -1;
+    const int zero = sum < thr;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        if (sum < thr) lv[k] = 0;
-        const int si = hv_scan_idx(S, 2, kind, k >> 2, k & 3);
-        if (lv[k] && si > last) last = si;
-        lev_dst[si] = (short)lv[k];
-        r[k] = hv_clip16((int)((unsigned)lv[k] << qsh));
+    for (int k = 0; k < 16; k++) { lv[k] = zero ? 0 : lv[k]; r[k] = hv_clip16((int)((unsigned)lv[k] << qsh)); }
+    constexpr int DG[16] = { 0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15 };   /* up-right diagonal  [ref :1130-1132] */
+    int o[16];
+    unsigned nzs = 0;
+#pragma unroll
+    for (int sc = 0; sc < 16; sc++) {
+        o[sc] = kind == 0 ? lv[DG[sc]] : (kind == 1 ? lv[sc] : lv[(sc & 3) * 4 + (sc >> 2)]);
+        nzs |= (unsigned)(o[sc] != 0) << sc;
     }
+    const int last = 31 - hv_clz(nzs);                           /* -1 when all levels are zero */
+    {
+        HvChunk c0, c1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            c0[i] = ((unsigned)o[2 * i] & 0xffffu) | ((unsigned)o[2 * i + 1] << 16);
+            c1[i] = ((unsigned)o[8 + 2 * i] & 0xffffu) | ((unsigned)o[9 + 2 * i] << 16);
+        }
+        ((HV_LDSP HvChunk *)lev_dst)[0] = c0; ((HV_LDSP HvChunk *)lev_dst)[1] = c1;
+    }
+    HV_NXT(2);
     /* inverse: columns with C^T (shift 7), rows (shift 12) */
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -1255,8 +1301,15 @@ static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int 
             const int rc = hv_clip8(res + p[i * 4 + j]);
             const int dd = (int)S.org[ty + i][tx + j] - rc;
             sse += dd * dd;
-            rec_dst[i * 4 + j] = (u8)rc;
+            p[i * 4 + j] = rc;
         }
+    {
+        HvChunk rc4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) rc4[i] = (unsigned)p[i * 4] | ((unsigned)p[i * 4 + 1] << 8) | ((unsigned)p[i * 4 + 2] << 16) | ((unsigned)p[i * 4 + 3] << 24);
+        *(HV_LDSP HvChunk *)rec_dst = rc4;
+    }
+    HV_NXT(3);
     last_out = last;
     return sse;
 }
@@ -1323,7 +1376,10 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
             hv_cg_load(S, g, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0), 1);
             const int nb = hv_cg_emit(S, wb, g, 0);
             HV_PROF2(S, 1);
-            hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb);
+            /* finished bytes are recorded over the tokens already consumed: record i is written no earlier than token i is
+               processed, and tokens are fetched at least eight ahead */
+            hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb, tk);
+            hv_cod_replay(c, (const HV_LDSP HvChunk *)tk);
             cost = hv_rdcost(q, S.nxn_sse[lane], hv_cod_bits(c));
             idx = lane;
         }
@@ -1400,7 +1456,7 @@ static HD void hv_level_begin(HvLds &S, const HvCu cu) {
    child (m == 0), the 27 jobs of the 32x32 CU during children 1..3 of the first and 1..2 of the second 16x16 CU.  The schedule is static and
    wave-uniform (SGPRs): no lane-dependent control flow may surround the calls, the jobs use wave-level shuffles. */
 #ifdef HEVCE_PROF_JOBS
-#define HV_JOBT(slot, call) do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); call; if (lane == 0) S.prof2[slot] += __builtin_amdgcn_s_memtime() - t0_; } while (0)
+#define HV_JOBT(slot, call) do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); call; if (lane == 0) S.prof2[8 + (slot)] += __builtin_amdgcn_s_memtime() - t0_; } while (0)
 #else
 #define HV_JOBT(slot, call) call
 #endif
@@ -1498,7 +1554,7 @@ static HD void hv_bin_cu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GL
 
 /* candidates of one CU after their TU jobs: engine state from the entry snapshot, binarisation, linking */
 static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu cu) {
-    const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, n = cu.n;
+    const int tid = hv_tid(), n = cu.n;
     HvLds::Level &L = S.lv[cu.lvl];
     HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
     HvGLev glev = (HvGLev)scr;
@@ -1583,9 +1639,12 @@ static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int
             hv_cod_load(c, L.tregs[t]);
             const int bits0 = hv_regs_bits(S.ent[lvl]);
             const HV_GLOBAL u16 *slots = (const HV_GLOBAL u16 *)(hv_level_scratch(im, lvl) + HV_TL * 1024 * 3) + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT;
+            HV_GLOBAL u16 *sink = (HV_GLOBAL u16 *)(hv_level_scratch(im, lvl) + HV_TL * 1024 * 3 + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT * 2) + (size_t)t * HEVCE_SINK_WORDS;
             int dead = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0) > hv_peek(&L.best_cost);
+            hv_cod_span(c);
             dead = hv_engine_slots(S, c, &L.tctx[0][t], slots, hv_slist(S, lvl, t), nlist, k, ci, dead, finish ? nullptr : &S.l0_active,
-                                   !finish && lvl == 0, q, L.tsse[t], bits0, &L.best_cost);
+                                   !finish && lvl == 0, q, L.tsse[t], bits0, &L.best_cost, sink);
+            hv_cod_replay(c, (const HV_GLOBAL HvChunk *)sink);
             hv_cod_store(L.tregs[t], c);
             if (dead) { L.tdead[t] = 1; L.tcost[t] = HV_I32MAX; L.tpos[t] = -1; }
             else if (k >= nlist) {
@@ -1722,7 +1781,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int tid = hv_tid(), q = im.qpd6, H = im.H, W = im.W;
     if (tid == 0) S.trace = im.trace;
     if (tid < 24) (&S.prof[0][0])[tid] = 0;
-    if (tid < 16) S.prof2[tid] = 0;
+    if (tid < 32) S.prof2[tid] = 0;
     BLOCK_SYNC();
     HV_TRACE(S, 0, 1);
     hv_init_tables(S, q, tid);
@@ -1825,6 +1884,6 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     }
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     if (im.trace && tid < 24) { ((unsigned long long *)im.trace)[tid] = (&S.prof[0][0])[tid]; }
-    if (im.trace && tid < 16) { ((unsigned long long *)im.trace)[24 + tid] = S.prof2[tid]; }
+    if (im.trace && tid < 32) { ((unsigned long long *)im.trace)[24 + tid] = S.prof2[tid]; }
 #endif
 }

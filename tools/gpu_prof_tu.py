@@ -13,7 +13,7 @@ img = wl.gen_g2(128, 256, 16)
 with hevce.Job([img.shape], 2) as job:
     job.upload(0, img); job.run()
     tr = job.trace(0)
-p2 = tr[48:80].view(np.uint64)[8:14].astype(float)
+p2 = tr[48:112].view(np.uint64)[16:22].astype(float)
 calls = {32: 18 + 0, 16: 36 + 9 * 4, 8: 80 + 20 * 4}[N] * 32     # hv_tu_job<N> calls per picture (32 CTUs)
 names = ("refs", "predict", "fwd cols", "fwd rows+quant", "inv cols", "inv rows+recon")
 print(f"hv_tu_job<{N}>: {p2.sum()/calls/1e3:.1f} k cycles per call")
