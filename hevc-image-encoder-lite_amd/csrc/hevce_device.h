@@ -840,7 +840,9 @@ static HD int hv_quant1(int q, int sh, int dsh, int av, int &d) {
         const int lv = hv_max(lv0 - t, 0);
         const int e = hv_abs(d - (lv << sh)) >> dsh;
         const int dist = ((e < 46340) ? e * e : HV_I32MAX) >> 7;
-        const int cst = hv_rd(w, dist, hv_level_rate(lv));
+        /* hv_rd() without its overflow guards: dist <= 2^24 - 1 and the level rate <= 1 140 576, so with wd <= 11 and
+           wb <= 29 neither product nor their sum can reach 2^31  [ref :177-185 saturates only beyond that] */
+        const int cst = w.wd * dist + w.wb * hv_level_rate(lv);
         const bool take = (lv0 - t >= 0) && (cst < best);
         best = take ? cst : best;
         pick = take ? lv : pick;
