@@ -556,19 +556,22 @@ template <typename WR> static HD void hv_emit_byp(WR &w, int bins, int len, int 
     hv_emit(w, HV_TOK_BYP | (n2 << 8) | ((bins >> n3) & ((1 << n2) - 1)), on && n2 > 0);
     hv_emit(w, HV_TOK_BYP | (n3 << 8) | (bins & ((1 << n3) - 1)), on && n3 > 0);
 }
-/* coeff_abs_level_remaining  [ref :1154-1169] */
+/* coeff_abs_level_remaining  [ref :1154-1169]: a prefix and a suffix, each put as its own bin string (chunks of <= 8).
+   short form (v < 3<<k, nearly always): prefix of (v>>k)+1 <= 3 bins, suffix of k <= 4 bins -- one chunk each, emitted
+   straight-line.  long form (Exp-Golomb escape, up to 3 + 2 chunks): rare, so it sits behind a branch. */
 template <typename WR> static HD void hv_emit_remainder(WR &w, int v, int k, int on) {
-    /* short form: v < 3<<k: prefix of (v>>k)+1 bins, suffix of k bins.  long form: Exp-Golomb escape */
     const int shortf = v < (3 << k);
     const int pre = v >> k;
-    /* escape: the reference subtracts 2^k, 2^(k+1), ... while the rest is >= 2^len; closed form of that loop */
-    const int w2 = hv_max(v - (3 << k), 0) + (1 << k);
-    const int len = 31 - hv_clz((unsigned)w2), u = w2 - (1 << len);
-    const int t = 4 + len - k;
-    const int pbins = shortf ? (1 << (pre + 1)) - 2 : (1 << t) - 2, plen = shortf ? pre + 1 : t;
-    const int sbins = shortf ? (v & ((1 << k) - 1)) : u, slen = shortf ? k : len;
-    hv_emit_byp(w, pbins, plen, on);
-    hv_emit_byp(w, sbins, slen, on);
+    hv_emit(w, HV_TOK_BYP | ((pre + 1) << 8) | ((2 << pre) - 2), on && shortf);
+    hv_emit(w, HV_TOK_BYP | (k << 8) | (v & ((1 << k) - 1)), on && shortf && k > 0);
+    if (on && !shortf) {
+        /* escape: the reference subtracts 2^k, 2^(k+1), ... while the rest is >= 2^len; closed form of that loop */
+        const int w2 = v - (3 << k) + (1 << k);
+        const int len = 31 - hv_clz((unsigned)w2), u = w2 - (1 << len);
+        const int t = 4 + len - k;
+        hv_emit_byp(w, (1 << t) - 2, t, 1);
+        hv_emit_byp(w, u, len, 1);
+    }
 }
 
 /* one 4x4 coefficient group of a transform block whose levels lie in SCAN ORDER at lev16[0..15]   [ref :1194-1268]
