@@ -199,6 +199,7 @@ struct alignas(16) HvLds {
 };
 
 typedef unsigned HvChunk __attribute__((vector_size(16), may_alias));   /* 16 bytes moved as one dwordx4: eight 16-bit tokens / records, packed levels, samples */
+typedef unsigned HvPair __attribute__((vector_size(8), may_alias));     /* 8 bytes moved as one dwordx2 */
 struct HvCod { int range; unsigned low; int nbits, nbytes, bufbyte, zeros, nout;
                int nev, zf; };   /* lockstep engines: finished bytes recorded but not yet accounted (hv_cod_replay), "a zero byte or a carry may be among them" */
 
@@ -697,7 +698,7 @@ template <typename SinkP> static HD void hv_engine_step(HvCod &c, int cv, const 
     const unsigned low_c = islps ? ((c.low + (unsigned)rm) << shl) : (c.low << shm);
     const int range_c = islps ? (lps << shl) : (rm << shm);
     const int sh_c = islps ? shl : shm;
-    const unsigned low_b = (c.low << nb) + (unsigned)c.range * (unsigned)bv;
+    const unsigned low_b = (c.low << nb) + (unsigned)hv_mul24(c.range, bv);      /* range < 2^9, bins < 2^8: the full-rate 24-bit multiply */
     c.low = isb ? low_b : low_c;
     c.range = isb ? c.range : range_c;
     c.nbits -= isb ? nb : sh_c;
@@ -895,7 +896,7 @@ static HD int hv_smoothed(int n, int m) {
 #define HV_TUT0() do { } while (0)
 #endif
 template <int N, typename LevP, typename RecP>
-static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
+static HD HvTuOut hv_tu_job(int wave, int lane, int q,
                             int ty, int tx,                         /* block origin, CTU-relative            */
                             int cu_y, int cu_x, int cu_n, const HV_LDSP u8 *inner, int edges,
                             int aL, int aLB, int aA, int aAR,       /* neighbour availability                */
@@ -1054,7 +1055,11 @@ static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
             }
             sum += hv_shfl_xor(sum, 1);                       /* the 4x4 group spans rows j&~3 .. j|3 = 4 adjacent lanes */
             sum += hv_shfl_xor(sum, 2);
-            int any = 0;
+            /* levels go out in scan order.  The 16 levels of this 4x4 group live in four adjacent lanes; they are put in scan
+               order through a 32-byte LDS tile per group (the reference-sample buffer is free by now), so that every lane
+               stores 8 contiguous bytes instead of four scattered 16-bit values */
+            int any = 0, cgs = 0;
+            HV_LDSP short *stage = (HV_LDSP short *)W.bord + (lane >> 2) * 16;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 if (sum < thr) lv[e] = 0;
@@ -1062,9 +1067,16 @@ static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
                 const int x = g * 4 + e;
                 const int si = hv_scan_idx(S, LG, kind, j, x);
                 if (lv[e] && si > last) last = si;
-                if (mode >= 0) lev_dst[si] = (short)lv[e];
+                stage[si & 15] = (short)lv[e];
+                cgs = si >> 4;
                 scr[j * RS + x] = (short)hv_clip16((int)((unsigned)lv[e] << qsh));
             }
+            WAVE_SYNC();
+            {
+                const HvPair four = *(const HV_LDSP HvPair *)(stage + (lane & 3) * 4);
+                if (mode >= 0) *(HV_GLOBAL HvPair *)((HV_GLOBAL short *)lev_dst + cgs * 16 + (lane & 3) * 4) = four;
+            }
+            WAVE_SYNC();
             any = any != 0;
             any |= hv_shfl_xor(any, 1);
             any |= hv_shfl_xor(any, 2);
@@ -1097,16 +1109,22 @@ static HDN HvTuOut hv_tu_job(int wave, int lane, int q,
 #pragma unroll
         for (int k = 0; k < N; k++) v[k] = scr[j * RS + k];
         const int *tab = HvTm<N>::t();
-        for (int x = 0; x < N; x++) {
-            int acc = 2048;
+        for (int x4 = 0; x4 < N; x4 += 4) {                      /* four samples = one 32-bit store */
+            unsigned pk = 0;
 #pragma unroll
-            for (int k = 0; k < N; k++) acc += hv_mul24(tab[x * N + k], v[k]);
-            const int r = hv_clip8(hv_clip16(acc >> 12) + pred[j * N + x]);
-            const int d = (int)S.org[ty + j][tx + x] - r;
-            sse += d * d;
-            if (mode >= 0) rec_dst[j * rec_stride + x] = (u8)r;
-            if (ecol && x == N - 1) ecol[j] = (u8)r;
-            if (erow && j == N - 1) erow[x] = (u8)r;
+            for (int e = 0; e < 4; e++) {
+                const int x = x4 + e;
+                int acc = 2048;
+#pragma unroll
+                for (int k = 0; k < N; k++) acc += hv_mul24(tab[x * N + k], v[k]);
+                const int r = hv_clip8(hv_clip16(acc >> 12) + pred[j * N + x]);
+                const int d = (int)S.org[ty + j][tx + x] - r;
+                sse += d * d;
+                pk |= (unsigned)r << (8 * e);
+                if (ecol && x == N - 1) ecol[j] = (u8)r;
+                if (erow && j == N - 1) erow[x] = (u8)r;
+            }
+            if (mode >= 0) *(HV_GLOBAL HvRingWord *)((HV_GLOBAL u8 *)rec_dst + j * rec_stride + x4) = pk;
         }
     }
     for (int s = 1; s < N; s <<= 1) sse += hv_shfl_xor(sse, s);
