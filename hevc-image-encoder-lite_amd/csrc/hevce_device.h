@@ -54,6 +54,7 @@ static HD int  hv_peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELA
 static HD int  hv_poll(const int *p) { return hv_peek(p); }      /* value other wavefronts are changing meanwhile */
 static HD void hv_atomic_dec(int *p) { atomicSub(p, 1); }
 static HD int  hv_mul24(int a, int b) { return __mul24(a, b); }
+static HD unsigned hv_umul24(unsigned a, unsigned b) { return __umul24(a, b); }   /* both < 2^24: low 32 bits of the product, full rate */
 static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v == 0 */
 static HD unsigned long long hv_ballot(int p) { return __ballot(p); }   /* one bit per active lane */
 static HD int  hv_clzll(unsigned long long v) { return __clzll((long long)v); }
@@ -843,10 +844,10 @@ static HD int hv_quant1(int q, int sh, int dsh, int av, int &d) {
     for (int t = 0; t < 3; t++) {
         const int lv = hv_max(lv0 - t, 0);
         const int e = hv_abs(d - (lv << sh)) >> dsh;
-        const int dist = ((e < 46340) ? e * e : HV_I32MAX) >> 7;
+        const int dist = ((e < 46340) ? (int)hv_umul24((unsigned)e, (unsigned)e) : HV_I32MAX) >> 7;   /* 46339^2 < 2^31 */
         /* hv_rd() without its overflow guards: dist <= 2^24 - 1 and the level rate <= 1 140 576, so with wd <= 11 and
            wb <= 29 neither product nor their sum can reach 2^31  [ref :177-185 saturates only beyond that] */
-        const int cst = w.wd * dist + w.wb * hv_level_rate(lv);
+        const int cst = (int)(hv_umul24((unsigned)w.wd, (unsigned)dist) + hv_umul24((unsigned)w.wb, (unsigned)hv_level_rate(lv)));   /* all operands < 2^24 */
         const bool take = (lv0 - t >= 0) && (cst < best);
         best = take ? cst : best;
         pick = take ? lv : pick;

@@ -60,4 +60,8 @@ static inline int hv_mul24(int a, int b) {
     if (a < -(1 << 23) || a >= (1 << 23) || b < -(1 << 23) || b >= (1 << 23)) { fprintf(stderr, "emu: mul24 operand out of range %d %d\n", a, b); abort(); }
     return a * b;
 }
+static inline unsigned hv_umul24(unsigned a, unsigned b) {
+    if (a >= (1u << 24) || b >= (1u << 24)) { fprintf(stderr, "emu: umul24 operand out of range %u %u\n", a, b); abort(); }
+    return a * b;
+}
 static inline int hv_clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
