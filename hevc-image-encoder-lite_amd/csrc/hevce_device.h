@@ -343,8 +343,10 @@ static HD void hv_cod_byte(HvCod &c, int lead, int on) {
 template <typename ChunkP> static HD void hv_cod_replay(HvCod &c, ChunkP sink8) {     /* sink as 16-byte chunks of eight records */
     const int n = c.nev;
     c.nev = 0; c.zf = 0;
+    HvChunk nxt = sink8[0];
     for (int base = 0; base < n; base += 8) {
-        const HvChunk ch = sink8[base >> 3];
+        const HvChunk ch = nxt;
+        nxt = sink8[(base >> 3) + 1];                             /* the sink may be in HBM: fetch ahead */
 #pragma unroll
         for (int j = 0; j < 8; j++) hv_cod_byte(c, (int)((ch[j >> 1] >> ((j & 1) << 4)) & 0xffffu), base + j < n);
     }
@@ -1707,11 +1709,26 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, H
         d[0] = v ? L.tsse[tid] : 0; d[1] = v ? L.tcost[tid] : 0; d[2] = v ? L.tdead[tid] : 0; d[3] = v ? L.tlen[tid] : 0;
     }
     /* ---------------- arg-min in the reference's order, later candidate wins ties ---------------- */
-    if (tid == 0) {
-        int best = HV_I32MAX, w = -1;
-        if (n > 8) best = hv_rdcost(q, S.split_sse, hv_regs_bits(S.com) - hv_regs_bits(S.ent[cu.lvl]));
-        for (int t = 0; t < ntrials; t++) if (!L.tdead[t] && best >= L.tcost[t]) { best = L.tcost[t]; w = t; }
-        S.winner = w;
+    if (hv_uni(wave) == 0) {
+        /* key = (cost, index): lowest cost, the highest index among equals [ref :1440 adopts on >=]; the split alternative
+           takes part as index -1 (any candidate of equal cost beats it); -2 = nothing yet.  Two candidates per lane, then a
+           butterfly over the wavefront. */
+        int bc = HV_I32MAX, bi = -2;
+        if (lane == 0 && n > 8) { bc = hv_rdcost(q, S.split_sse, hv_regs_bits(S.com) - hv_regs_bits(S.ent[cu.lvl])); bi = -1; }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int t = lane + 64 * u;
+            const bool ok = t < ntrials && !L.tdead[hv_min(t, HV_TL - 1)];
+            const int c = L.tcost[hv_min(t, HV_TL - 1)];
+            const bool take = ok && (bi == -2 || c < bc || (c == bc && t > bi));
+            bc = take ? c : bc; bi = take ? t : bi;
+        }
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int oc = hv_shfl_xor(bc, sft), oi = hv_shfl_xor(bi, sft);
+            const bool take = oi != -2 && (bi == -2 || oc < bc || (oc == bc && oi > bi));
+            bc = take ? oc : bc; bi = take ? oi : bi;
+        }
+        if (lane == 0) S.winner = bi < 0 ? -1 : bi;
     }
     BLOCK_SYNC();
     const int w = S.winner;
