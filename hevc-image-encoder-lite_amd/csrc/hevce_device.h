@@ -184,7 +184,7 @@ struct alignas(16) HvLds {
     alignas(16) short nxn_lev[35][16];                      /* 16-byte rows: written / read as vectors */
     alignas(16) u8    nxn_rec[35][16];
     int   nxn_sse[35], nxn_last[35], nxn_sig[35];
-    short nxn_bestlev[4][16];
+    alignas(16) short nxn_bestlev[4][16];
     alignas(16) u16 nxn_tok[35][144];                                 /* per candidate: its token stream (header + one group), 16-byte rows */
     u8    nxn_crec[8][8];
     u8    nxn_line[35][16];                                 /* per mode: angular reference line r(-4..9) */
@@ -585,6 +585,14 @@ template <typename WR> static HD void hv_emit_remainder(WR &w, int v, int k, int
    hv_cg_emit() writes the tokens, given that fact about the PREVIOUS coded group (g1).
    Straight-line code: fixed trip counts, unconditional stores, conditional counts -- threads binarising different groups
    stay converged and nothing is a branch. */
+/* pointer to 16-byte chunks in the same address space as a pointer to levels */
+template <typename T> struct HvAsChunk;
+#ifdef HEVCE_EMU
+template <> struct HvAsChunk<const short *> { typedef const HvChunk *type; };
+#else
+template <> struct HvAsChunk<const HV_GLOBAL short *> { typedef const HV_GLOBAL HvChunk *type; };
+template <> struct HvAsChunk<const HV_LDSP short *> { typedef const HV_LDSP HvChunk *type; };
+#endif
 struct HvCg { int v[16]; unsigned nzm; int coded, cgs, nb, first_cg, at_last_cg, start, n, kind, g1own; };
 template <typename LP> static HD void hv_cg_load(const HvLds &S, HvCg &g, LP lev16, int n, int lg, int kind, int cg, int last, u64 cgsig, int valid) {
     const int cg_last = last >> 4;
@@ -600,9 +608,14 @@ template <typename LP> static HD void hv_cg_load(const HvLds &S, HvCg &g, LP lev
     g.nb = (below << 1) | right;
     g.start = g.at_last_cg ? (last & 15) : 15;
     unsigned nzm = 0, bigm = 0;
+    /* the group's 16 levels are 32 contiguous, 32-byte aligned bytes: two 16-byte loads instead of sixteen 2-byte ones
+       (always readable: scratch is allocated for every group; what a group without levels holds is ignored) */
+    const HvChunk lo = ((typename HvAsChunk<LP>::type)lev16)[0], hi = ((typename HvAsChunk<LP>::type)lev16)[1];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        g.v[k] = g.cgs ? (int)lev16[k] : 0;
+        const unsigned d = (k < 8 ? lo : hi)[(k & 7) >> 1];
+        const int val = (int)(short)(d >> ((k & 1) << 4));
+        g.v[k] = g.cgs ? val : 0;
         nzm |= (unsigned)(g.v[k] != 0) << k;
         bigm |= (unsigned)(hv_abs(g.v[k]) > 1) << k;
     }
