@@ -561,20 +561,23 @@ template <typename WR> static HD void hv_emit_byp(WR &w, int bins, int len, int 
     hv_emit(w, HV_TOK_BYP | (n3 << 8) | (bins & ((1 << n3) - 1)), on && n3 > 0);
 }
 /* coeff_abs_level_remaining  [ref :1154-1169]: a prefix and a suffix, each put as its own bin string (chunks of <= 8).
-   short form (v < 3<<k, nearly always): prefix of (v>>k)+1 <= 3 bins, suffix of k <= 4 bins -- one chunk each, emitted
-   straight-line.  long form (Exp-Golomb escape, up to 3 + 2 chunks): rare, so it sits behind a branch. */
+   short form (v < 3<<k): prefix of (v>>k)+1 <= 3 bins, suffix of k <= 4 bins.  long form (Exp-Golomb escape): prefix of
+   t = 4+len-k bins, suffix of len bins.  Whenever both strings fit one chunk (always in the short form, and in the long
+   form up to v of a few hundred) the two tokens are emitted straight-line; only longer strings, which are rare even per
+   wavefront, go through the chunking code behind a branch. */
 template <typename WR> static HD void hv_emit_remainder(WR &w, int v, int k, int on) {
     const int shortf = v < (3 << k);
-    const int pre = v >> k;
-    hv_emit(w, HV_TOK_BYP | ((pre + 1) << 8) | ((2 << pre) - 2), on && shortf);
-    hv_emit(w, HV_TOK_BYP | (k << 8) | (v & ((1 << k) - 1)), on && shortf && k > 0);
-    if (on && !shortf) {
-        /* escape: the reference subtracts 2^k, 2^(k+1), ... while the rest is >= 2^len; closed form of that loop */
-        const int w2 = v - (3 << k) + (1 << k);
-        const int len = 31 - hv_clz((unsigned)w2), u = w2 - (1 << len);
-        const int t = 4 + len - k;
-        hv_emit_byp(w, (1 << t) - 2, t, 1);
-        hv_emit_byp(w, u, len, 1);
+    /* escape: the reference subtracts 2^k, 2^(k+1), ... while the rest is >= 2^len; closed form of that loop */
+    const int w2 = hv_max(v - (3 << k), 0) + (1 << k);
+    const int len = 31 - hv_clz((unsigned)w2), u = w2 - (1 << len);
+    const int plen = shortf ? (v >> k) + 1 : 4 + len - k, pbins = (1 << plen) - 2;
+    const int slen = shortf ? k : len, sbins = shortf ? (v & ((1 << k) - 1)) : u;
+    const int simple = (plen <= 8) & (slen <= 8);
+    hv_emit(w, HV_TOK_BYP | (plen << 8) | (pbins & 0xff), on && simple);
+    hv_emit(w, HV_TOK_BYP | (slen << 8) | (sbins & 0xff), on && simple && slen > 0);
+    if (on && !simple) {
+        hv_emit_byp(w, pbins, plen, 1);
+        hv_emit_byp(w, sbins, slen, 1);
     }
 }
 
