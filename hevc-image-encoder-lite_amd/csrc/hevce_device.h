@@ -156,6 +156,7 @@ struct alignas(16) HvLds {
     alignas(8) unsigned ctab[128][2];                       /* [context byte]: { four LPS ranges (one byte per range quarter), next byte after LPS | after MPS << 8 } */
     u8  sigtab[35][16];                                     /* sig_coeff_flag context per scan position of a 4x4 group, by (size class, scan, neighbours, first group) */                         /* context byte after an MPS / LPS  [ref HEVCe.c:701-702] */
     u8  d4pos[16], d4idx[16];                               /* diagonal scan inside a 4x4 group: idx->(y<<2|x), (y<<2|x)->idx */
+    short ang[36], invang[36];                              /* intra angle / inverse angle per mode: a per-lane read of a __constant__ table is a waterfall of scalar loads */
     u8  cgpos[3][64], cgidx[3][64];                         /* group order for 2x2 / 4x4 / 8x8 groups: idx->(gy<<3|gx), gy*ncg+gx->idx */
     u8  ctx_fresh[HEVCE_NCTXP];
     /* committed coder state, entry snapshots per CU level (0: 8x8, 1: 16x16, 2: 32x32) */
@@ -1017,7 +1018,7 @@ static HD HvTuOut hv_tu_job(int wave, int lane, int q,
         } else {
             /* angular: reference line r(k): k>0 main side, k==0 corner, k<0 side samples projected by the inverse angle */
             const bool horiz = m < 18;
-            const int ang = hv_ang[m], inv = hv_invang[m];
+            const int ang = S.ang[m], inv = S.invang[m];
             const u8 *mainr = horiz ? l : a, *sider = horiz ? a : l;
             for (int i = 0; i < N; i++) {
                 const int step = horiz ? j : i, along = horiz ? i : j;
@@ -1224,40 +1225,20 @@ static HDN void hv_job_chain(int wave, int lane, int q, HvCu cu, int grp, HvGLev
 #endif
 static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int ty, int tx, int m, HV_LDSP short *lev_dst, HV_LDSP u8 *rec_dst, int &last_out) {
     HV_NXT0();
+    /* All five prediction forms are evaluated by every lane and the lane's own is selected at the end: lane = mode, so a
+       branch per form would make the wavefront walk all of them anyway, plus the merging of sixteen registers per branch.
+       Pure horizontal / vertical (10 / 26) are the angular form with angle 0 plus their edge filter. */
     const u8 *l = b + 1, *a = b + 9;
     const int c = b[0];
-    int p[16];
-    if (m == 0) {
-        const int lN = l[4], aN = a[4];
+    int L[5], A[5];
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) p[i * 4 + j] = (4 + (3 - j) * l[i] + (j + 1) * aN + (3 - i) * a[j] + (i + 1) * lN) >> 3;
-    } else if (m == 1) {
-        int dc = 4;
-#pragma unroll
-        for (int i = 0; i < 4; i++) dc += l[i] + a[i];
-        dc >>= 3;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                p[i * 4 + j] = (i == 0 && j == 0) ? (2 + 2 * dc + l[0] + a[0]) >> 2 : (i == 0) ? (2 + 3 * dc + a[j]) >> 2 : (j == 0) ? (2 + 3 * dc + l[i]) >> 2 : dc;
-    } else if (m == 10) {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) p[i * 4 + j] = (i == 0) ? hv_clip8(l[0] + ((a[j] - c) >> 1)) : l[i];
-    } else if (m == 26) {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) p[i * 4 + j] = (j == 0) ? hv_clip8(a[0] + ((l[i] - c) >> 1)) : a[j];
-    } else {
+    for (int i = 0; i < 5; i++) { L[i] = l[i]; A[i] = a[i]; }
+    int p[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    {
         /* angular: this mode's reference line r(k), k = -4..9, is laid out once (r(k>0) main side, r(0) corner, r(k<0) the
            side samples projected through the inverse angle [ref :353-364]); the pixel loop then only indexes it */
         const bool horiz = m < 18;
-        const int ang = hv_ang[m], inv = hv_invang[m];
+        const int ang = S.ang[m], inv = S.invang[m];
         const u8 *mainr = horiz ? l : a, *sider = horiz ? a : l;
         u8 *line = line_buf + 4;
 #pragma unroll
@@ -1275,9 +1256,28 @@ static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int 
             for (int al = 0; al < 4; al++) {
                 const int k1 = oi + al + 1;
                 const int v = ((32 - of) * line[k1] + of * line[k1 + 1] + 16) >> 5;
-                if (horiz) p[al * 4 + st] = v; else p[st * 4 + al] = v;
+                p[al * 4 + st] = horiz ? v : p[al * 4 + st];
+                p[st * 4 + al] = horiz ? p[st * 4 + al] : v;
             }
         }
+    }
+    {
+        int dc = 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) dc += L[i] + A[i];
+        dc >>= 3;
+        const bool planar = m == 0, isdc = m == 1, hor = m == 10, ver = m == 26;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int pl = (4 + (3 - j) * L[i] + (j + 1) * A[4] + (3 - i) * A[j] + (i + 1) * L[4]) >> 3;
+                const int dv = (i == 0 && j == 0) ? (2 + 2 * dc + L[0] + A[0]) >> 2 : (i == 0) ? (2 + 3 * dc + A[j]) >> 2 : (j == 0) ? (2 + 3 * dc + L[i]) >> 2 : dc;
+                int v = p[i * 4 + j];
+                if (i == 0) v = hor ? hv_clip8(L[0] + ((A[j] - c) >> 1)) : v;      /* edge filters of the pure directions */
+                if (j == 0) v = ver ? hv_clip8(A[0] + ((L[i] - c) >> 1)) : v;
+                p[i * 4 + j] = planar ? pl : (isdc ? dv : v);
+            }
     }
     HV_NXT(0);
     int r[16], t[16];
@@ -1787,6 +1787,7 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, H
 /* --------------------------------------------------------------------------------------------- */
 static HD void hv_init_tables(HvLds &S, int q, int tid) {
     if (tid < 64) { S.lps4[tid] = hv_lps4[tid]; S.lpsnext[tid] = hv_lpsnext[tid]; }
+    if (tid >= 384 && tid < 384 + 35) { S.ang[tid - 384] = hv_ang[tid - 384]; S.invang[tid - 384] = hv_invang[tid - 384]; }
     if (tid >= 256 && tid < 384) {
         const int cv = tid - 256, st = cv >> 1, mps = cv & 1;
         const int nm = st < 62 ? cv + 2 : cv, nl = st == 0 ? (mps ^ 1) : ((hv_lpsnext[st] << 1) | mps);
