@@ -508,7 +508,7 @@ static HD int hv_last_min(int g) { return g < 4 ? g : (2 + (g & 1)) << ((g >> 1)
 
 /* TU header slot: cbf_luma (unless the caller is the NxN sub-search, which codes bare residuals) and the position of
    the last significant coefficient   [ref :1038-1087, 1192].  Straight-line like the CU header (<= 25 tokens). */
-template <typename WR> static HD int hv_tokenize_tu(const HvLds &S, WR &w, int n, int lg, int kind_scan, int with_cbf, int cbf_ctx, int cbf, int last) {
+template <int MAXG = 9, typename WR> static HD int hv_tokenize_tu(const HvLds &S, WR &w, int n, int lg, int kind_scan, int with_cbf, int cbf_ctx, int cbf, int last) {   /* MAXG: largest prefix group the caller's block sizes can reach (4x4: 3) */
     hv_emit(w, HV_CT(cbf_ctx, cbf), with_cbf);
     const int on0 = cbf || !with_cbf;
     int gy, gx, iy, ix;
@@ -519,17 +519,17 @@ template <typename WR> static HD int hv_tokenize_tu(const HvLds &S, WR &w, int n
     int ty = kind_scan == 2 ? x : y, tx = kind_scan == 2 ? y : x;
     const int ggy = hv_last_group(ty), ggx = hv_last_group(tx), gmax = 2 * lg - 1;       /* gmax = group of n - 1 */
 #pragma unroll
-    for (int i = 0; i < 9; i++) hv_emit(w, HV_CT(CX_LASTX + 5 * cls + (i >> sh), 1), on0 && i < ggx);
+    for (int i = 0; i < MAXG; i++) hv_emit(w, HV_CT(CX_LASTX + 5 * cls + (i >> sh), 1), on0 && i < ggx);
     hv_emit(w, HV_CT(CX_LASTX + 5 * cls + (ggx >> sh), 0), on0 && ggx < gmax);
 #pragma unroll
-    for (int i = 0; i < 9; i++) hv_emit(w, HV_CT(CX_LASTY + 5 * cls + (i >> sh), 1), on0 && i < ggy);
+    for (int i = 0; i < MAXG; i++) hv_emit(w, HV_CT(CX_LASTY + 5 * cls + (i >> sh), 1), on0 && i < ggy);
     hv_emit(w, HV_CT(CX_LASTY + 5 * cls + (ggy >> sh), 0), on0 && ggy < gmax);
     const int nx = ggx > 3 ? ((ggx - 2) >> 1) : 0, ny = ggy > 3 ? ((ggy - 2) >> 1) : 0;   /* suffix bits, one chunk per bit */
     tx -= hv_last_min(ggx); ty -= hv_last_min(ggy);
 #pragma unroll
-    for (int i = 2; i >= 0; i--) hv_emit(w, HV_TOK_BYP | (1 << 8) | ((tx >> i) & 1), on0 && i < nx);
+    for (int i = 2; i >= 0; i--) if (MAXG > 3) hv_emit(w, HV_TOK_BYP | (1 << 8) | ((tx >> i) & 1), on0 && i < nx);   /* groups <= 3 have no suffix */
 #pragma unroll
-    for (int i = 2; i >= 0; i--) hv_emit(w, HV_TOK_BYP | (1 << 8) | ((ty >> i) & 1), on0 && i < ny);
+    for (int i = 2; i >= 0; i--) if (MAXG > 3) hv_emit(w, HV_TOK_BYP | (1 << 8) | ((ty >> i) & 1), on0 && i < ny);
     hv_tok_checkpoint(w);
     return hv_tok_finish(w);
 }
@@ -1412,7 +1412,7 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
             const int ks = hv_scan_kind(4, lane);
             /* the two slots are laid out so that their tokens are contiguous from tk[8]; one group: no set memory */
             HvTokW<HV_LDSP u16 *> wa = { tk, 0 };
-            const int na = hv_tokenize_tu(S, wa, 4, 2, ks, 0, 0, 1, S.nxn_last[lane]);
+            const int na = hv_tokenize_tu<3>(S, wa, 4, 2, ks, 0, 0, 1, S.nxn_last[lane]);
             HvTokW<HV_LDSP u16 *> wb = { tk + na, 0 };
             HvCg g;
             hv_cg_load(S, g, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0), 1);
