@@ -56,6 +56,7 @@ static HD void hv_atomic_dec(int *p) { atomicSub(p, 1); }
 static HD int  hv_mul24(int a, int b) { return __mul24(a, b); }
 static HD unsigned hv_umul24(unsigned a, unsigned b) { return __umul24(a, b); }   /* both < 2^24: low 32 bits of the product, full rate */
 static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v == 0 */
+static HD int  hv_clz_nz(unsigned v) { return __builtin_clz(v); }   /* v != 0: the bare instruction */
 static HD unsigned long long hv_ballot(int p) { return __ballot(p); }   /* one bit per active lane */
 static HD int  hv_clzll(unsigned long long v) { return __clzll((long long)v); }
 #endif
@@ -311,14 +312,14 @@ static HD void hv_cod_span(HvCod &c) {
     c.zf = (c.zeros > 0) | ((c.bufbyte & 0xff) == 0) | ((c.bufbyte & 0xff) == 0xff) | (c.nbytes > 1);
 }
 template <typename SinkP> static HD void hv_cod_carry_rec(HvCod &c, SinkP sink) {
-    const int need = c.nbits < 12;
-    const unsigned lead = c.low >> ((24 - c.nbits) & 31);       /* meaningful when need: shift 13..24 */
-    if (need) sink[c.nev] = (u16)lead;
-    const int nb8 = c.nbits + 8;
-    c.low = need ? (c.low & (0xffffffffu >> nb8)) : c.low;
-    c.nbits = need ? nb8 : c.nbits;
-    c.zf |= need & ((((lead & 0xff) == 0) | ((lead >> 8) != 0)) ? 1 : 0);
-    c.nev += need;
+    if (c.nbits < 12) {                                          /* one region under the lanes' mask: a store and four updates */
+        const unsigned lead = c.low >> (24 - c.nbits);
+        sink[c.nev] = (u16)lead;
+        c.nbits += 8;
+        c.low &= 0xffffffffu >> c.nbits;
+        c.zf |= (int)(((lead - 1u) | lead) >> 8);                 /* non-zero iff the byte is 0 or a carry came with it (lead is 9 bits) */
+        c.nev++;
+    }
 }
 /* exact bookkeeping of one finished byte (`on` = there is one): hv_cod_carry without the register part; the common case
    straight-line, the flush of a run of 0xff bytes a (rare) branch */
@@ -711,7 +712,7 @@ template <typename SinkP> static HD void hv_engine_step(HvCod &c, int cv, const 
     const int isb = (tok >> 15) & 1;
     const int nb = (tok >> 8) & 15, bv = tok & 0xff;
     const int lps = (int)((ct.lps4 >> (((c.range >> 6) & 3) << 3)) & 0xff);
-    const int shl = hv_clz((unsigned)lps) - 23;                  /* lps in 6..240: 1..6 */
+    const int shl = hv_clz_nz((unsigned)lps) - 23;               /* lps in 6..240: 1..6 */
     const int islps = (((tok >> 14) & 1) ^ cv) & 1;
     const int rm = c.range - lps;
     const int shm = (rm < 256) ? 1 : 0;

@@ -65,3 +65,4 @@ static inline unsigned hv_umul24(unsigned a, unsigned b) {
     return a * b;
 }
 static inline int hv_clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
+static inline int hv_clz_nz(unsigned v) { if (!v) { fprintf(stderr, "emu: clz_nz(0)\n"); abort(); } return __builtin_clz(v); }
