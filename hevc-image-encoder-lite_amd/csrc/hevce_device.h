@@ -53,6 +53,8 @@ static HD void hv_atomic_min(int *p, int v) { atomicMin(p, v); }
 static HD int  hv_peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 static HD int  hv_poll(const int *p) { return hv_peek(p); }      /* value other wavefronts are changing meanwhile */
 static HD void hv_atomic_dec(int *p) { atomicSub(p, 1); }
+static HD void hv_flag_clear(int *p) { __hip_atomic_store(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define HV_FENCE_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
 static HD int  hv_mul24(int a, int b) { return __mul24(a, b); }
 static HD unsigned hv_umul24(unsigned a, unsigned b) { return __umul24(a, b); }   /* both < 2^24: low 32 bits of the product, full rate */
 static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v == 0 */
@@ -195,6 +197,7 @@ struct alignas(16) HvLds {
     /* control */
     int winner, split_sse;
     int l0_active;                                          /* 8x8 candidates whose engines still run in this engine phase */
+    int nxn_busy;                                           /* 1 while wavefront 0 walks the NxN chain of the current 8x8 CU */
     unsigned long long prof[3][8];
     unsigned long long prof2[32];                           /* HEVCE_PROF: inside the NxN job (tu jobs, tokenise, engine, select) */
     int *trace;
@@ -1491,6 +1494,7 @@ static HD void hv_level_begin(HvLds &S, const HvCu cu) {
     }
     if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = 0; L.tlen[tid] = 0; }
     if (n == 8) for (int k = tid; k < 8 * 8; k += HV_NTHREADS) (&S.nxn_crec[0][0])[k] = 0;
+    if (n == 8 && tid == 0) S.nxn_busy = 1;
 }
 
 /* TU-job phase of the 8x8 CU number m (0..3) of the 16x16 CU number k16 (0..3).  Wavefront 0 walks the NxN chain, the
@@ -1498,6 +1502,8 @@ static HD void hv_level_begin(HvLds &S, const HvCu cu) {
    jobs of the enclosing CUs, which only depend on samples outside those CUs: all 14 jobs of the 16x16 CU during its first
    child (m == 0), the 27 jobs of the 32x32 CU during children 1..3 of the first and 1..2 of the second 16x16 CU.  The schedule is static and
    wave-uniform (SGPRs): no lane-dependent control flow may surround the calls, the jobs use wave-level shuffles. */
+static HD void hv_run_engines(HvLds &S, const HevceImageDesc &im, int mask, int *shared, int nw, int ew);
+
 #ifdef HEVCE_PROF_JOBS
 #define HV_JOBT(slot, call) do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); call; if (lane == 0) S.prof2[8 + (slot)] += __builtin_amdgcn_s_memtime() - t0_; } while (0)
 #else
@@ -1508,7 +1514,12 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     const int wv = hv_uni(wave);
     k16 = hv_uni(k16); m = hv_uni(m);
     HV_GLOBAL u8 *s0 = hv_level_scratch(im, 0), *s1 = hv_level_scratch(im, 1), *s2 = hv_level_scratch(im, 2);
-    if (wv == 0) { hv_job_nxn(wave, lane, q, c8); return; }
+    if (wv == 0) {
+        hv_job_nxn(wave, lane, q, c8);
+        HV_FENCE_RELEASE();
+        if (lane == 0) hv_flag_clear(&S.nxn_busy);               /* releases the riders below */
+        return;
+    }
     if (wv == 4) return;                                         /* shares its SIMD with wavefront 0: stays idle */
     const int w1 = wv < 4 ? wv - 1 : wv - 2;                     /* work slot 0..5 */
     HvGLev l0 = (HvGLev)s0, l1 = (HvGLev)s1, l2 = (HvGLev)s2;
@@ -1530,6 +1541,10 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         if (idx < 9) HV_JOBT(12, hv_job_chain<16>(wave, lane, q, c32, idx, l2, r2));
         else if (idx < 27) HV_JOBT(13, hv_job_single<32>(wave, lane, q, c32, idx - 9, l2, r2));
     }
+    /* whatever time the NxN chain still takes: the candidates of the enclosing CUs that are already prepared ride on, twelve
+       lanes per CU level and job wavefront, until wavefront 0 clears S.nxn_busy (16x16 candidates exist from their CU's
+       second round on, 32x32 candidates after round (1,2)) */
+    hv_run_engines(S, im, (m >= 1 ? 2 : 0) | ((k16 >= 2 || (k16 == 1 && m == 3)) ? 4 : 0), &S.nxn_busy, 6, w1);
 }
 
 /* binarisation work items of hv_prepare_streams (slot numbering: see there) */
@@ -1655,23 +1670,16 @@ static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu
     HV_PROF(S, cu.lvl, 5);
 }
 
-/* Engines run on HV_ENG_WAVES wavefronts only -- one per SIMD, so that each issues at full rate (the loop is a single
-   dependent instruction stream; two engine wavefronts on one SIMD would take turns).  Lanes 0..17 of such a wavefront:
-   8x8 candidates; 18..35: 16x16; 36..53: 32x32 (candidate = lane' * 4 + wave).
-   mask: bit l set = level l takes part; `finish` lifts the quota (used when a parent is decided). */
-#ifndef HV_ENG_WAVES
-#define HV_ENG_WAVES 4
-#endif
-#ifndef HV_ENG_WAVE_OF
-#define HV_ENG_WAVE_OF(w) (w)                                 /* engine wavefront index -> hardware wavefront */
-#endif
-static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int finish) {
-    const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
-    HV_PROF_T0();
-    const int per = HV_TL / HV_ENG_WAVES;
-    int ew = -1;
-    for (int i = 0; i < HV_ENG_WAVES; i++) if (HV_ENG_WAVE_OF(i) == wave) ew = i;
-    const int lvl = lane / per, t = (lane % per) * HV_ENG_WAVES + ew;
+/* Arithmetic engines of the candidates, lane = candidate.  `nw` wavefronts take part, this one is number `ew` (or -1: none);
+   each carries HV_TL / nw candidates per CU level: lanes [0, per) 8x8 candidates, [per, 2 per) 16x16, [2 per, 3 per) 32x32,
+   candidate = lane' * nw + ew.  mask: bit l set = level l takes part.
+   shared == nullptr: everything selected runs to its end.  Otherwise *shared is a count that other lanes / wavefronts bring
+   to zero, and the candidates ride along until it gets there (8x8 candidates, if selected, run to their end and are the
+   ones that count it down). */
+static HD void hv_run_engines(HvLds &S, const HevceImageDesc &im, int mask, int *shared, int nw, int ew) {
+    const int lane = hv_tid() & 63, q = im.qpd6;
+    const int per = HV_TL / nw;
+    const int lvl = lane / per, t = (lane % per) * nw + ew;
     if (ew >= 0 && lvl < 3 && ((mask >> lvl) & 1)) {
         HvLds::Level &L = S.lv[lvl];
         const int ntrials = (lvl == 0) ? 71 : 70;
@@ -1685,8 +1693,8 @@ static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int
             HV_GLOBAL u16 *sink = (HV_GLOBAL u16 *)(hv_level_scratch(im, lvl) + HV_TL * 1024 * 3 + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT * 2) + (size_t)t * HEVCE_SINK_WORDS;
             int dead = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0) > hv_peek(&L.best_cost);
             hv_cod_span(c);
-            dead = hv_engine_slots(S, c, &L.tctx[0][t], slots, hv_slist(S, lvl, t), nlist, k, ci, dead, finish ? nullptr : &S.l0_active,
-                                   !finish && lvl == 0, q, L.tsse[t], bits0, &L.best_cost, sink);
+            dead = hv_engine_slots(S, c, &L.tctx[0][t], slots, hv_slist(S, lvl, t), nlist, k, ci, dead, shared,
+                                   shared && lvl == 0, q, L.tsse[t], bits0, &L.best_cost, sink);
             hv_cod_replay(c, (const HV_GLOBAL HvChunk *)sink);
             hv_cod_store(L.tregs[t], c);
             if (dead) { L.tdead[t] = 1; L.tcost[t] = HV_I32MAX; L.tpos[t] = -1; }
@@ -1698,6 +1706,15 @@ static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int
             } else L.tpos[t] = k | (ci << 8);
         }
     }
+}
+/* engine phase of its own: four wavefronts, one per SIMD (the loop is a single dependent instruction stream; two engine
+   wavefronts on one SIMD would take turns).  finish = 0: the 8x8 candidates run to their end, the candidates of the
+   enclosing CUs ride along for as long as that takes (S.l0_active counts the 8x8 engines still running);
+   finish = 1 (a 16x16 / 32x32 CU is decided): what the ride-along left runs to its end. */
+static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int finish) {
+    const int wave = hv_tid() >> 6;
+    HV_PROF_T0();
+    hv_run_engines(S, im, mask, finish ? nullptr : &S.l0_active, 4, wave < 4 ? wave : -1);
     BLOCK_SYNC();
     HV_PROF(S, 0, 6);
 }
