@@ -1497,56 +1497,6 @@ static HD void hv_level_begin(HvLds &S, const HvCu cu) {
     if (n == 8 && tid == 0) S.nxn_busy = 1;
 }
 
-/* TU-job phase of the 8x8 CU number m (0..3) of the 16x16 CU number k16 (0..3).  Wavefront 0 walks the NxN chain, the
-   longest job by far (wavefront 4, on the same SIMD, stays idle); the other six run the 8x8 CU's eight block jobs AND, in the time wavefront 0 leaves them, the
-   jobs of the enclosing CUs, which only depend on samples outside those CUs: all 14 jobs of the 16x16 CU during its first
-   child (m == 0), the 27 jobs of the 32x32 CU during children 1..3 of the first and 1..2 of the second 16x16 CU.  The schedule is static and
-   wave-uniform (SGPRs): no lane-dependent control flow may surround the calls, the jobs use wave-level shuffles. */
-static HD void hv_run_engines(HvLds &S, const HevceImageDesc &im, int mask, int *shared, int nw, int ew);
-
-#ifdef HEVCE_PROF_JOBS
-#define HV_JOBT(slot, call) do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); call; if (lane == 0) S.prof2[8 + (slot)] += __builtin_amdgcn_s_memtime() - t0_; } while (0)
-#else
-#define HV_JOBT(slot, call) call
-#endif
-static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m) {
-    const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
-    const int wv = hv_uni(wave);
-    k16 = hv_uni(k16); m = hv_uni(m);
-    HV_GLOBAL u8 *s0 = hv_level_scratch(im, 0), *s1 = hv_level_scratch(im, 1), *s2 = hv_level_scratch(im, 2);
-    if (wv == 0) {
-        hv_job_nxn(wave, lane, q, c8);
-        HV_FENCE_RELEASE();
-        if (lane == 0) hv_flag_clear(&S.nxn_busy);               /* releases the riders below */
-        return;
-    }
-    if (wv == 4) return;                                         /* shares its SIMD with wavefront 0: stays idle */
-    const int w1 = wv < 4 ? wv - 1 : wv - 2;                     /* work slot 0..5 */
-    HvGLev l0 = (HvGLev)s0, l1 = (HvGLev)s1, l2 = (HvGLev)s2;
-    HvGRec r0 = (HvGRec)(s0 + HV_TL * 1024 * 2), r1 = (HvGRec)(s1 + HV_TL * 1024 * 2), r2 = (HvGRec)(s2 + HV_TL * 1024 * 2);
-    /* 8x8: 3 TU-split chains (16 modes each) on slots 0..2, 5 single TUs (8 modes each) on slots 3..5 */
-    if (w1 < 3) HV_JOBT(8, hv_job_chain<4>(wave, lane, q, c8, w1, l0, r0));
-    else {
-        HV_JOBT(9, hv_job_single<8>(wave, lane, q, c8, 2 * (w1 - 3), l0, r0));
-        if (w1 < 5) HV_JOBT(9, hv_job_single<8>(wave, lane, q, c8, 2 * (w1 - 3) + 1, l0, r0));
-    }
-    if (m == 0) {
-        /* 16x16: 5 chains (8 modes each) on slots 0..4, 9 single TUs (4 modes each): one each on slots 0..4, four on slot 5 */
-        if (w1 < 5) { HV_JOBT(10, hv_job_chain<8>(wave, lane, q, c16, w1, l1, r1)); HV_JOBT(11, hv_job_single<16>(wave, lane, q, c16, w1, l1, r1)); }
-        else for (int j = 5; j < 9; j++) HV_JOBT(11, hv_job_single<16>(wave, lane, q, c16, j, l1, r1));
-    } else if (k16 < 2 && !(k16 == 1 && m == 3)) {
-        /* 32x32: 9 chains (4 modes each, ~180 k cycles) and 18 single TUs (2 modes each, ~160 k): one per work slot in the
-           five phases (k16, m) = (0,1) (0,2) (0,3) (1,1) (1,2); a second one would outlast the NxN chain (~270 k) */
-        const int idx = (k16 * 3 + m - 1) * 6 + w1;
-        if (idx < 9) HV_JOBT(12, hv_job_chain<16>(wave, lane, q, c32, idx, l2, r2));
-        else if (idx < 27) HV_JOBT(13, hv_job_single<32>(wave, lane, q, c32, idx - 9, l2, r2));
-    }
-    /* whatever time the NxN chain still takes: the candidates of the enclosing CUs that are already prepared ride on, twelve
-       lanes per CU level and job wavefront, until wavefront 0 clears S.nxn_busy (16x16 candidates exist from their CU's
-       second round on, 32x32 candidates after round (1,2)) */
-    hv_run_engines(S, im, (m >= 1 ? 2 : 0) | ((k16 >= 2 || (k16 == 1 && m == 3)) ? 4 : 0), &S.nxn_busy, 6, w1);
-}
-
 /* binarisation work items of hv_prepare_streams (slot numbering: see there) */
 static HD HV_LDSP u16 *hv_slist(HvLds &S, int lvl, int t) { return lvl == 0 ? (HV_LDSP u16 *)S.slist0[t] : lvl == 1 ? (HV_LDSP u16 *)S.slist1[t] : (HV_LDSP u16 *)S.slist2[t]; }
 static HD const HV_LDSP u16 *hv_slist(const HvLds &S, int lvl, int t) { return lvl == 0 ? (const HV_LDSP u16 *)S.slist0[t] : lvl == 1 ? (const HV_LDSP u16 *)S.slist1[t] : (const HV_LDSP u16 *)S.slist2[t]; }
@@ -1610,6 +1560,19 @@ static HD void hv_bin_cu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GL
     S.shdr[t][0] = (u8)hv_tokenize_cu(w, cu.n, cu.lg, kind, L.split_inc, pm);
 }
 
+/* link: the list of candidate t's non-empty slots; the engine walks it */
+static HD void hv_build_slist(HvLds &S, HvLds::Level &L, int n, int lvl, int t) {
+    const int nslots = hv_trial_slots(n, t);
+    HV_LDSP u16 *ls = hv_slist(S, lvl, t);
+    int k = 0;
+    for (int f = 0; f < nslots; f++) {
+        const int ch = S.shdr[t][f];
+        ls[k] = (u16)(f | (ch << 8));
+        k += (ch != 0);
+    }
+    L.tlen[t] = k; L.tpos[t] = 0;
+}
+
 /* candidates of one CU after their TU jobs: engine state from the entry snapshot, binarisation, linking */
 static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu cu) {
     const int tid = hv_tid(), n = cu.n;
@@ -1623,23 +1586,21 @@ static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu
     for (int k = tid; k < HEVCE_NCTXP * HV_TL; k += HV_NTHREADS) L.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[cu.lvl][k / HV_TL];
     if (tid < ntrials) L.tregs[tid] = S.ent[cu.lvl];
 
+    if (n == 16) { BLOCK_SYNC(); return; }                      /* binarised by the job wavefronts (hv_bin_own) */
+
     /* ---------------- binarisation: one work item per slot of every candidate (data-parallel) ----------------
        [ref :1434-1435, 1470-1471, 1540-1541 call the syntax writers per candidate; here only their bins are formed]
        slot f of candidate t: f = 0 CU header; then per transform block (1 for candidates 0..34, 4 otherwise) a header slot
        followed by its 4x4 groups from the highest scan index down -- the order the engine consumes them.  Work items are
        dense and grouped by kind so that the threads of a wavefront execute the same binarisation path. */
     if (n == 8) {
-        /* 280 group items on wavefronts 0..4; wavefronts 5..7 meanwhile: 179 block headers, 71 CU headers and the four
-           groups of the NxN candidate (levels in LDS, a different instantiation -- kept off the wavefronts above) */
-        if (tid < 320) hv_bin_group(S, L, cu, gtok, glev, tid, tid < 280);
-        HV_PROF3L(0);
+        /* candidates 0..69 were binarised by the wavefronts that ran their block jobs (hv_bin_own8); left is candidate 70,
+           the outcome of the NxN chain: four groups (levels in LDS), four block headers, one CU header -- on three wavefronts */
         const int w = tid - 320;
-        if (w >= 8 && w < 8 + 179) {
-            const int j = w - 8;
-            hv_bin_tu_header(S, L, cu, gtok, j < 35 ? j : 35 + ((j - 35) >> 2), j < 35 ? 0 : ((j - 35) & 3));
-        }
-        if (w >= 0 && w < 71) hv_bin_cu_header(S, L, cu, gtok, w);
-        if (w >= 188) hv_bin_group_nxn(S, L, cu, gtok, w - 188);
+        if (w >= 0 && w < 4) hv_bin_group_nxn(S, L, cu, gtok, w);
+        if (w >= 64 && w < 68) hv_bin_tu_header(S, L, cu, gtok, 70, w - 64);
+        if (w == 128) hv_bin_cu_header(S, L, cu, gtok, 70);
+        HV_PROF3L(0);
     } else {
         const int ncg_cu = (n >> 2) * (n >> 2);
         for (int i0 = 0; i0 < 70 * ncg_cu; i0 += HV_NTHREADS) hv_bin_group(S, L, cu, gtok, glev, i0 + tid, i0 + tid < 70 * ncg_cu);
@@ -1651,19 +1612,7 @@ static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu
     BLOCK_SYNC();
     HV_PROF3L(1);
     /* ---------------- link: per candidate the list of its non-empty slots; the engine walks it ---------------- */
-    for (int t = tid; t < ntrials; t += HV_NTHREADS) {
-        const int nslots = hv_trial_slots(n, t);
-        HV_LDSP u16 *ls = hv_slist(S, cu.lvl, t);
-        int k = 0;
-        for (int f = 0; f < nslots; f++) {
-            const int ch = S.shdr[t][f];
-            ls[k] = (u16)(f | (ch << 8));
-            k += (ch != 0);
-        }
-        L.tlen[t] = k; L.tpos[t] = 0;
-    }
-    BLOCK_SYNC();
-    HV_PROF3L(2);
+    for (int t = (n == 8 ? 70 + tid : tid); t < ntrials; t += HV_NTHREADS) hv_build_slist(S, L, n, cu.lvl, t);   /* 8x8: 0..69 are done */
     if (tid == 0 && n == 8) S.l0_active = 71;                   /* see hv_engine_phase */
     BLOCK_SYNC();
     HV_PROF3L(3);
@@ -1717,6 +1666,83 @@ static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int
     hv_run_engines(S, im, mask, finish ? nullptr : &S.l0_active, 4, wave < 4 ? wave : -1);
     BLOCK_SYNC();
     HV_PROF(S, 0, 6);
+}
+
+/* A job wavefront binarises the candidates [tb, tb + tc) that its own block jobs have just produced, and builds their slot
+   lists: nothing here depends on another wavefront, so it happens in the shadow of the NxN chain without any
+   synchronisation.  Group items: 64 / (groups per CU) candidates per pass, lane = candidate * groups + group (the groups of
+   one transform block in adjacent, aligned lanes: see hv_bin_group). */
+static HD void hv_bin_own(HvLds &S, const HevceImageDesc &im, const HvCu cu, int tb, int tc) {
+    const int lane = hv_tid() & 63;
+    HvLds::Level &L = S.lv[cu.lvl];
+    HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
+    HV_GLOBAL u16 *gtok = (HV_GLOBAL u16 *)(scr + HV_TL * 1024 * 3);
+    const int ncg = (cu.n >> 2) * (cu.n >> 2), per = 64 / ncg;
+    tb = hv_uni(tb); tc = hv_uni(tc);
+    HV_FENCE_RELEASE();                                          /* the jobs' levels in HBM, their results in LDS */
+    WAVE_SYNC();
+    for (int c0 = 0; c0 < tc; c0 += per)
+        hv_bin_group(S, L, cu, gtok, (HvGLev)scr, (tb + c0 + lane / ncg) * ncg + lane % ncg, c0 + lane / ncg < tc);
+    for (int j = lane; j < tc * 4; j += 64) {
+        const int t = tb + (j >> 2), tu = j & 3;
+        if (t >= 35 || tu == 0) hv_bin_tu_header(S, L, cu, gtok, t, tu);
+    }
+    for (int j = lane; j < tc; j += 64) hv_bin_cu_header(S, L, cu, gtok, tb + j);
+    WAVE_SYNC();
+    for (int j = lane; j < tc; j += 64) hv_build_slist(S, L, cu.n, cu.lvl, tb + j);
+}
+
+/* TU-job phase of the 8x8 CU number m (0..3) of the 16x16 CU number k16 (0..3).  Wavefront 0 walks the NxN chain, the
+   longest job by far; wavefront 4, on the same SIMD, stays idle.  The other six ("job wavefronts", work slots 0..5):
+     1. the 8x8 CU's eight block jobs, then the binarisation of the candidates they produced (hv_bin_own8);
+     2. the jobs of the enclosing CUs, which only depend on samples outside those CUs: all 14 jobs of the 16x16 CU during
+        its first child (m == 0), the 27 jobs of the 32x32 CU one per slot in rounds (0,1) (0,2) (0,3) (1,1) (1,2);
+     3. in the time the NxN chain still takes, the prepared candidates of the enclosing CUs ride on.
+   The schedule is static and wave-uniform (SGPRs): no lane-dependent control flow may surround the jobs (wave shuffles). */
+#ifdef HEVCE_PROF_JOBS
+#define HV_JOBT(slot, call) do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); call; if (lane == 0) S.prof2[8 + (slot)] += __builtin_amdgcn_s_memtime() - t0_; } while (0)
+#else
+#define HV_JOBT(slot, call) call
+#endif
+static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m) {
+    const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
+    const int wv = hv_uni(wave);
+    k16 = hv_uni(k16); m = hv_uni(m);
+    HV_GLOBAL u8 *s0 = hv_level_scratch(im, 0), *s1 = hv_level_scratch(im, 1), *s2 = hv_level_scratch(im, 2);
+    if (wv == 0) {
+        hv_job_nxn(wave, lane, q, c8);
+        HV_FENCE_RELEASE();
+        if (lane == 0) hv_flag_clear(&S.nxn_busy);               /* releases the riders below */
+        return;
+    }
+    if (wv == 4) return;                                         /* shares its SIMD with wavefront 0: stays idle */
+    const int w1 = wv < 4 ? wv - 1 : wv - 2;                     /* work slot 0..5 */
+    HvGLev l0 = (HvGLev)s0, l1 = (HvGLev)s1, l2 = (HvGLev)s2;
+    HvGRec r0 = (HvGRec)(s0 + HV_TL * 1024 * 2), r1 = (HvGRec)(s1 + HV_TL * 1024 * 2), r2 = (HvGRec)(s2 + HV_TL * 1024 * 2);
+    /* 8x8: 3 TU-split chains (16 modes each) on slots 0..2, 5 single TUs (8 modes each) on slots 3..5 */
+    if (w1 < 3) HV_JOBT(8, hv_job_chain<4>(wave, lane, q, c8, w1, l0, r0));
+    else {
+        HV_JOBT(9, hv_job_single<8>(wave, lane, q, c8, 2 * (w1 - 3), l0, r0));
+        if (w1 < 5) HV_JOBT(9, hv_job_single<8>(wave, lane, q, c8, 2 * (w1 - 3) + 1, l0, r0));
+    }
+    hv_bin_own(S, im, c8, w1 < 3 ? 35 + 16 * w1 : 16 * (w1 - 3), hv_min(16, (w1 < 3 ? 70 : 35) - (w1 < 3 ? 35 + 16 * w1 : 16 * (w1 - 3))));
+    if (m == 0) {
+        /* 16x16: 5 chains (8 modes each) on slots 0..4, 9 single TUs (4 modes each): one each on slots 0..4, four on slot 5 */
+        if (w1 < 5) { HV_JOBT(10, hv_job_chain<8>(wave, lane, q, c16, w1, l1, r1)); HV_JOBT(11, hv_job_single<16>(wave, lane, q, c16, w1, l1, r1)); }
+        else for (int j = 5; j < 9; j++) HV_JOBT(11, hv_job_single<16>(wave, lane, q, c16, j, l1, r1));
+    } else if (k16 < 2 && !(k16 == 1 && m == 3)) {
+        /* 32x32: 9 chains (4 modes each, ~180 k cycles) and 18 single TUs (2 modes each, ~160 k): one per work slot in the
+           five phases (k16, m) = (0,1) (0,2) (0,3) (1,1) (1,2); a second one would outlast the NxN chain (~270 k) */
+        const int idx = (k16 * 3 + m - 1) * 6 + w1;
+        if (idx < 9) HV_JOBT(12, hv_job_chain<16>(wave, lane, q, c32, idx, l2, r2));
+        else if (idx < 27) HV_JOBT(13, hv_job_single<32>(wave, lane, q, c32, idx - 9, l2, r2));
+    }
+    /* whatever time the NxN chain still takes: the candidates of the enclosing CUs that are already prepared ride on, twelve
+       lanes per CU level and job wavefront, until wavefront 0 clears S.nxn_busy (16x16 candidates exist from their CU's
+       second round on, 32x32 candidates after round (1,2)) */
+    /* the 16x16 CU's candidates (their jobs ran in the previous round): twelve per job wavefront, any wavefront will do */
+    if (m == 1) hv_bin_own(S, im, c16, 12 * w1, hv_min(12, 70 - 12 * w1));
+    hv_run_engines(S, im, (m >= 2 ? 2 : 0) | ((k16 >= 2 || (k16 == 1 && m == 3)) ? 4 : 0), &S.nxn_busy, 6, w1);
 }
 
 static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HevceRecord *rec, int32_t *dump) {
@@ -1934,7 +1960,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     hv_prepare_streams(S, im, cu);
                     if (m == 0) hv_prepare_streams(S, im, c16);
                     if (k == 1 && m == 2) hv_prepare_streams(S, im, c32);     /* its jobs ran in five phases up to this one */
-                    hv_engine_phase(S, im, (k == 0 || (k == 1 && m < 2)) ? 3 : 7, 0);
+                    hv_engine_phase(S, im, 1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m >= 2)) ? 4 : 0), 0);
                 }
                 hv_decide_cu(S, im, cu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr);
             }
