@@ -1422,6 +1422,9 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
             hv_cg_load(S, g, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0), 1);
             const int nb = hv_cg_emit(S, wb, g, 0);
             HV_PROF2(S, 1);
+            /* last block, only its engine to go: tell the candidates riding in the other wavefronts to wind up, so that they are
+               at the workgroup barrier when this wavefront gets there */
+            if (s == 3 && lane == 0) hv_flag_clear(&S.nxn_busy);
             /* finished bytes are recorded over the tokens already consumed: record i is written no earlier than token i is
                processed, and tokens are fetched at least eight ahead */
             hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb, tk);
@@ -1710,9 +1713,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     k16 = hv_uni(k16); m = hv_uni(m);
     HV_GLOBAL u8 *s0 = hv_level_scratch(im, 0), *s1 = hv_level_scratch(im, 1), *s2 = hv_level_scratch(im, 2);
     if (wv == 0) {
-        hv_job_nxn(wave, lane, q, c8);
-        HV_FENCE_RELEASE();
-        if (lane == 0) hv_flag_clear(&S.nxn_busy);               /* releases the riders below */
+        hv_job_nxn(wave, lane, q, c8);                          /* clears S.nxn_busy shortly before its end */
         return;
     }
     if (wv == 4) return;                                         /* shares its SIMD with wavefront 0: stays idle */
