@@ -1500,6 +1500,12 @@ static HD void hv_level_begin(HvLds &S, const HvCu cu) {
     if (n == 8 && tid == 0) S.nxn_busy = 1;
 }
 
+/* chunks per slot of the candidates being binarised: rows of HEVCE_TOKEN_SLOTS + 2 bytes, row 0 = candidate t0.  Either the
+   workgroup's S.shdr (t0 = 0) or, when a wavefront binarises a range of candidates on its own, a piece of that
+   wavefront's scratch tile -- the counts only live from the work items to hv_build_slist. */
+struct HvCnt { HV_LDSP u8 *p; int t0; };
+static HD HV_LDSP u8 &hv_cnt(const HvCnt &cn, int t, int f) { return cn.p[(t - cn.t0) * (HEVCE_TOKEN_SLOTS + 2) + f]; }
+
 /* binarisation work items of hv_prepare_streams (slot numbering: see there) */
 static HD HV_LDSP u16 *hv_slist(HvLds &S, int lvl, int t) { return lvl == 0 ? (HV_LDSP u16 *)S.slist0[t] : lvl == 1 ? (HV_LDSP u16 *)S.slist1[t] : (HV_LDSP u16 *)S.slist2[t]; }
 static HD const HV_LDSP u16 *hv_slist(const HvLds &S, int lvl, int t) { return lvl == 0 ? (const HV_LDSP u16 *)S.slist0[t] : lvl == 1 ? (const HV_LDSP u16 *)S.slist1[t] : (const HV_LDSP u16 *)S.slist2[t]; }
@@ -1507,7 +1513,7 @@ static HD const HV_LDSP u16 *hv_slist(const HvLds &S, int lvl, int t) { return l
 /* Group item number `item` (candidate-major, coding order inside a transform block).  EVERY lane of the wavefront calls
    this (valid = 0 beyond the last item): the groups of one transform block sit in adjacent lanes, aligned to their
    count, so the "previous coded group had a level > 1" memory  [ref :1222-1226] is two wave-wide ballots away. */
-static HD void hv_bin_group(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, HvGLev glev, int item, int valid) {
+static HD void hv_bin_group(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, HvGLev glev, const HvCnt &cn, int item, int valid) {
     const int ncg_cu = (cu.n >> 2) * (cu.n >> 2);
     item = valid ? item : 0;
     const int t = item / ncg_cu, gi = item % ncg_cu;
@@ -1523,29 +1529,29 @@ static HD void hv_bin_group(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL
     const u64 before = bnz & ((((u64)1 << (lane & (ncgt - 1))) - 1) << (lane & ~(ncgt - 1)));   /* coded earlier, same block */
     const int g1 = before ? (int)((bg1 >> (63 - hv_clzll(before))) & 1) : 0;
     if (!valid) return;
-    u8 &sh = S.shdr[t][1 + tu * (1 + ncgt) + 1 + r];
+    HV_LDSP u8 &sh = hv_cnt(cn, t, 1 + tu * (1 + ncgt) + 1 + r);
     if (!cbf) { sh = 0; return; }
     HvTokRing w = hv_tok_ring(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt) + 1 + r) * HV_SLOT);
     sh = (u8)hv_cg_emit(S, w, g, g1);
 }
-static HD void hv_bin_group_nxn(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, int tu) {   /* candidate 70: levels in LDS */
+static HD void hv_bin_group_nxn(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, const HvCnt &cn, int tu) {   /* candidate 70: levels in LDS */
     const int t = 70;
-    u8 &sh = S.shdr[t][1 + tu * 2 + 1];
+    HV_LDSP u8 &sh = hv_cnt(cn, t, 1 + tu * 2 + 1);
     if (!L.tinfo[t][tu].cbf) { sh = 0; return; }
     HvTokRing w = hv_tok_ring(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * 2 + 1) * HV_SLOT);
     HvCg g;
     hv_cg_load(S, g, (const HV_LDSP short *)&S.nxn_bestlev[tu][0], 4, 2, hv_scan_kind(4, S.nxn_modes[tu]), 0, L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig, 1);
     sh = (u8)hv_cg_emit(S, w, g, 0);
 }
-static HD void hv_bin_tu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, int t, int tu) {
+static HD void hv_bin_tu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, const HvCnt &cn, int t, int tu) {
     const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
     const int tn = kind == 0 ? cu.n : (cu.n >> 1), tlg = kind == 0 ? cu.lg : cu.lg - 1, ncgt = (tn >> 2) * (tn >> 2);
     const int md = kind == 0 ? t : kind == 1 ? t - 35 : S.nxn_modes[tu];
     HvTokRing w = hv_tok_ring(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt)) * HV_SLOT);
-    S.shdr[t][1 + tu * (1 + ncgt)] = (u8)hv_tokenize_tu(S, w, tn, tlg, hv_scan_kind(tn, md), 1, kind == 0 ? CX_YCBF + 1 : CX_YCBF,
+    hv_cnt(cn, t, 1 + tu * (1 + ncgt)) = (u8)hv_tokenize_tu(S, w, tn, tlg, hv_scan_kind(tn, md), 1, kind == 0 ? CX_YCBF + 1 : CX_YCBF,
                                                          L.tinfo[t][tu].cbf, L.tinfo[t][tu].last);
 }
-static HD void hv_bin_cu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, int t) {
+static HD void hv_bin_cu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, const HvCnt &cn, int t) {
     const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
     const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
     HvModes pm;
@@ -1560,16 +1566,16 @@ static HD void hv_bin_cu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GL
         pm.left[3] = pm.mode[2];  pm.above[3] = pm.mode[1];
     }
     HvTokRing w = hv_tok_ring(S, gtok + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT);
-    S.shdr[t][0] = (u8)hv_tokenize_cu(w, cu.n, cu.lg, kind, L.split_inc, pm);
+    hv_cnt(cn, t, 0) = (u8)hv_tokenize_cu(w, cu.n, cu.lg, kind, L.split_inc, pm);
 }
 
 /* link: the list of candidate t's non-empty slots; the engine walks it */
-static HD void hv_build_slist(HvLds &S, HvLds::Level &L, int n, int lvl, int t) {
+static HD void hv_build_slist(HvLds &S, HvLds::Level &L, const HvCnt &cn, int n, int lvl, int t) {
     const int nslots = hv_trial_slots(n, t);
     HV_LDSP u16 *ls = hv_slist(S, lvl, t);
     int k = 0;
     for (int f = 0; f < nslots; f++) {
-        const int ch = S.shdr[t][f];
+        const int ch = hv_cnt(cn, t, f);
         ls[k] = (u16)(f | (ch << 8));
         k += (ch != 0);
     }
@@ -1584,12 +1590,13 @@ static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu
     HvGLev glev = (HvGLev)scr;
     HV_GLOBAL u16 *gtok = (HV_GLOBAL u16 *)(scr + HV_TL * 1024 * 3);
     const int ntrials = (n == 8) ? 71 : 70;
+    const HvCnt cn = { (HV_LDSP u8 *)&S.shdr[0][0], 0 };
     HV_PROF_T0();
     /* candidates start from the CU's entry snapshot  [ref :1423-1424] */
     for (int k = tid; k < HEVCE_NCTXP * HV_TL; k += HV_NTHREADS) L.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[cu.lvl][k / HV_TL];
     if (tid < ntrials) L.tregs[tid] = S.ent[cu.lvl];
 
-    if (n == 16) { BLOCK_SYNC(); return; }                      /* binarised by the job wavefronts (hv_bin_own) */
+    if (n >= 16) { BLOCK_SYNC(); return; }                      /* binarised by the job wavefronts in a later round (hv_bin_own) */
 
     /* ---------------- binarisation: one work item per slot of every candidate (data-parallel) ----------------
        [ref :1434-1435, 1470-1471, 1540-1541 call the syntax writers per candidate; here only their bins are formed]
@@ -1600,22 +1607,22 @@ static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu
         /* candidates 0..69 were binarised by the wavefronts that ran their block jobs (hv_bin_own8); left is candidate 70,
            the outcome of the NxN chain: four groups (levels in LDS), four block headers, one CU header -- on three wavefronts */
         const int w = tid - 320;
-        if (w >= 0 && w < 4) hv_bin_group_nxn(S, L, cu, gtok, w);
-        if (w >= 64 && w < 68) hv_bin_tu_header(S, L, cu, gtok, 70, w - 64);
-        if (w == 128) hv_bin_cu_header(S, L, cu, gtok, 70);
+        if (w >= 0 && w < 4) hv_bin_group_nxn(S, L, cu, gtok, cn, w);
+        if (w >= 64 && w < 68) hv_bin_tu_header(S, L, cu, gtok, cn, 70, w - 64);
+        if (w == 128) hv_bin_cu_header(S, L, cu, gtok, cn, 70);
         HV_PROF3L(0);
     } else {
         const int ncg_cu = (n >> 2) * (n >> 2);
-        for (int i0 = 0; i0 < 70 * ncg_cu; i0 += HV_NTHREADS) hv_bin_group(S, L, cu, gtok, glev, i0 + tid, i0 + tid < 70 * ncg_cu);
+        for (int i0 = 0; i0 < 70 * ncg_cu; i0 += HV_NTHREADS) hv_bin_group(S, L, cu, gtok, glev, cn, i0 + tid, i0 + tid < 70 * ncg_cu);
         HV_PROF3L(0);
         for (int item = tid; item < 35 * 5; item += HV_NTHREADS)
-            hv_bin_tu_header(S, L, cu, gtok, item < 35 ? item : 35 + ((item - 35) >> 2), item < 35 ? 0 : ((item - 35) & 3));
-        for (int t = tid; t < 70; t += HV_NTHREADS) hv_bin_cu_header(S, L, cu, gtok, t);
+            hv_bin_tu_header(S, L, cu, gtok, cn, item < 35 ? item : 35 + ((item - 35) >> 2), item < 35 ? 0 : ((item - 35) & 3));
+        for (int t = tid; t < 70; t += HV_NTHREADS) hv_bin_cu_header(S, L, cu, gtok, cn, t);
     }
     BLOCK_SYNC();
     HV_PROF3L(1);
     /* ---------------- link: per candidate the list of its non-empty slots; the engine walks it ---------------- */
-    for (int t = (n == 8 ? 70 + tid : tid); t < ntrials; t += HV_NTHREADS) hv_build_slist(S, L, n, cu.lvl, t);   /* 8x8: 0..69 are done */
+    for (int t = (n == 8 ? 70 + tid : tid); t < ntrials; t += HV_NTHREADS) hv_build_slist(S, L, cn, n, cu.lvl, t);   /* 8x8: 0..69 are done */
     if (tid == 0 && n == 8) S.l0_active = 71;                   /* see hv_engine_phase */
     BLOCK_SYNC();
     HV_PROF3L(3);
@@ -1682,17 +1689,19 @@ static HD void hv_bin_own(HvLds &S, const HevceImageDesc &im, const HvCu cu, int
     HV_GLOBAL u16 *gtok = (HV_GLOBAL u16 *)(scr + HV_TL * 1024 * 3);
     const int ncg = (cu.n >> 2) * (cu.n >> 2), per = 64 / ncg;
     tb = hv_uni(tb); tc = hv_uni(tc);
+    /* slot counts of these (<= 16) candidates: behind the token ring in this wavefront's scratch tile */
+    const HvCnt cn = { (HV_LDSP u8 *)&S.ws[hv_tid() >> 6] + 4096, tb };
     HV_FENCE_RELEASE();                                          /* the jobs' levels in HBM, their results in LDS */
     WAVE_SYNC();
     for (int c0 = 0; c0 < tc; c0 += per)
-        hv_bin_group(S, L, cu, gtok, (HvGLev)scr, (tb + c0 + lane / ncg) * ncg + lane % ncg, c0 + lane / ncg < tc);
+        hv_bin_group(S, L, cu, gtok, (HvGLev)scr, cn, (tb + c0 + lane / ncg) * ncg + lane % ncg, c0 + lane / ncg < tc);
     for (int j = lane; j < tc * 4; j += 64) {
         const int t = tb + (j >> 2), tu = j & 3;
-        if (t >= 35 || tu == 0) hv_bin_tu_header(S, L, cu, gtok, t, tu);
+        if (t >= 35 || tu == 0) hv_bin_tu_header(S, L, cu, gtok, cn, t, tu);
     }
-    for (int j = lane; j < tc; j += 64) hv_bin_cu_header(S, L, cu, gtok, tb + j);
+    for (int j = lane; j < tc; j += 64) hv_bin_cu_header(S, L, cu, gtok, cn, tb + j);
     WAVE_SYNC();
-    for (int j = lane; j < tc; j += 64) hv_build_slist(S, L, cu.n, cu.lvl, tb + j);
+    for (int j = lane; j < tc; j += 64) hv_build_slist(S, L, cn, cu.n, cu.lvl, tb + j);
 }
 
 /* TU-job phase of the 8x8 CU number m (0..3) of the 16x16 CU number k16 (0..3).  Wavefront 0 walks the NxN chain, the
@@ -1743,7 +1752,8 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
        second round on, 32x32 candidates after round (1,2)) */
     /* the 16x16 CU's candidates (their jobs ran in the previous round): twelve per job wavefront, any wavefront will do */
     if (m == 1) hv_bin_own(S, im, c16, 12 * w1, hv_min(12, 70 - 12 * w1));
-    hv_run_engines(S, im, (m >= 2 ? 2 : 0) | ((k16 >= 2 || (k16 == 1 && m == 3)) ? 4 : 0), &S.nxn_busy, 6, w1);
+    if (k16 == 1 && m == 3) hv_bin_own(S, im, c32, 12 * w1, hv_min(12, 70 - 12 * w1));    /* the 32x32 CU's: its last jobs ran in round (1,2) */
+    hv_run_engines(S, im, (m >= 2 ? 2 : 0) | (k16 >= 2 ? 4 : 0), &S.nxn_busy, 6, w1);
 }
 
 static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HevceRecord *rec, int32_t *dump) {
@@ -1961,7 +1971,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     hv_prepare_streams(S, im, cu);
                     if (m == 0) hv_prepare_streams(S, im, c16);
                     if (k == 1 && m == 2) hv_prepare_streams(S, im, c32);     /* its jobs ran in five phases up to this one */
-                    hv_engine_phase(S, im, 1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m >= 2)) ? 4 : 0), 0);
+                    hv_engine_phase(S, im, 1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0), 0);
                 }
                 hv_decide_cu(S, im, cu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr);
             }
