@@ -182,7 +182,6 @@ struct alignas(16) HvLds {
         int best_cost;                                      /* lowest cost of a COMPLETED candidate (pruning bound) */
         int split_inc, ml, ma;                              /* neighbour context read at the CU's entry [ref :1369-1373] */
     } lv[3];
-    u8  shdr[HV_TL][HEVCE_TOKEN_SLOTS + 2];                 /* chunks per slot of the level being prepared (transient) */
     u16 slist0[HV_TL][10], slist1[HV_TL][22], slist2[HV_TL][70];   /* per level and candidate: non-empty slots, slot | chunks << 8 */
     /* NxN sub-search */
     alignas(16) short nxn_lev[35][16];                      /* 16-byte rows: written / read as vectors */
@@ -194,6 +193,7 @@ struct alignas(16) HvLds {
     u8    nxn_line[35][16];                                 /* per mode: angular reference line r(-4..9) */
     u8    nxn_bord[20];                                     /* raw reference samples of the current 4x4: corner, left[8], above[8] */
     int   nxn_modes[4];
+    u8    nxn_ctx[HEVCE_NCTXP][HV_TL];                      /* context columns of the NxN chain's 35 modes (fresh per 4x4 block) */
     /* control */
     int winner, split_sse;
     int l0_active;                                          /* 8x8 candidates whose engines still run in this engine phase */
@@ -1400,11 +1400,10 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
         }
         WAVE_SYNC();
         HV_PROF2(S, 0);
-        /* rate of every candidate: lane = mode  [ref :1505-1519]; residual_coding is written even for an all-zero block.
-           The 8x8 level's context columns are free at this point (they are re-initialised before its engine phase). */
+        /* rate of every candidate: lane = mode  [ref :1505-1519]; residual_coding is written even for an all-zero block */
         int cost = HV_I32MAX, idx = -1;
         if (lane < HEVCE_NMODES) {
-            u8 *cx = &L.tctx[0][lane];
+            u8 *cx = &S.nxn_ctx[0][lane];                          /* the chain's own context columns (same layout as a level's) */
             for (int k = 0; k < 3; k++) { *HV_CX(CX_LASTX + k) = S.ctx_fresh[CX_LASTX + k]; *HV_CX(CX_LASTY + k) = S.ctx_fresh[CX_LASTY + k]; }
             for (int k = 0; k < 9; k++) *HV_CX(CX_SIG + k) = S.ctx_fresh[CX_SIG + k];
             for (int k = 0; k < 4; k++) *HV_CX(CX_ONE + k) = S.ctx_fresh[CX_ONE + k];
@@ -1497,16 +1496,18 @@ static HD void hv_level_begin(HvLds &S, const HvCu cu) {
     }
     if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = 0; L.tlen[tid] = 0; }
     if (n == 8) for (int k = tid; k < 8 * 8; k += HV_NTHREADS) (&S.nxn_crec[0][0])[k] = 0;
-    if (n == 8 && tid == 0) S.nxn_busy = 1;
+    if (n == 8 && tid == 0) { S.nxn_busy = 1; S.l0_active = 71; }
 }
 
-/* chunks per slot of the candidates being binarised: rows of HEVCE_TOKEN_SLOTS + 2 bytes, row 0 = candidate t0.  Either the
-   workgroup's S.shdr (t0 = 0) or, when a wavefront binarises a range of candidates on its own, a piece of that
-   wavefront's scratch tile -- the counts only live from the work items to hv_build_slist. */
+/* chunks per slot of the candidates a wavefront is binarising: rows of HEVCE_TOKEN_SLOTS + 2 bytes, row 0 = candidate t0, in
+   a piece of that wavefront's scratch tile -- the counts only live from the work items to hv_build_slist, and wavefronts
+   work on different ranges of candidates (and CU levels) at the same time. */
 struct HvCnt { HV_LDSP u8 *p; int t0; };
 static HD HV_LDSP u8 &hv_cnt(const HvCnt &cn, int t, int f) { return cn.p[(t - cn.t0) * (HEVCE_TOKEN_SLOTS + 2) + f]; }
 
-/* binarisation work items of hv_prepare_streams (slot numbering: see there) */
+/* binarisation work items (slot f of candidate t: f = 0 CU header; then per transform block -- 1 for candidates 0..34, 4
+   otherwise -- a header slot followed by its 4x4 groups from the highest scan index down: the order the engine consumes them)
+   [ref :1434-1435, 1470-1471, 1540-1541 call the syntax writers per candidate; here only their bins are formed] */
 static HD HV_LDSP u16 *hv_slist(HvLds &S, int lvl, int t) { return lvl == 0 ? (HV_LDSP u16 *)S.slist0[t] : lvl == 1 ? (HV_LDSP u16 *)S.slist1[t] : (HV_LDSP u16 *)S.slist2[t]; }
 static HD const HV_LDSP u16 *hv_slist(const HvLds &S, int lvl, int t) { return lvl == 0 ? (const HV_LDSP u16 *)S.slist0[t] : lvl == 1 ? (const HV_LDSP u16 *)S.slist1[t] : (const HV_LDSP u16 *)S.slist2[t]; }
 
@@ -1582,50 +1583,15 @@ static HD void hv_build_slist(HvLds &S, HvLds::Level &L, const HvCnt &cn, int n,
     L.tlen[t] = k; L.tpos[t] = 0;
 }
 
-/* candidates of one CU after their TU jobs: engine state from the entry snapshot, binarisation, linking */
-static HD void hv_prepare_streams(HvLds &S, const HevceImageDesc &im, const HvCu cu) {
-    const int tid = hv_tid(), n = cu.n;
+/* candidates of a 16x16 / 32x32 CU start from its entry snapshot  [ref :1423-1424]: context columns and coder registers
+   (their binarisation happens in the job wavefronts, hv_bin_own) */
+static HD void hv_level_contexts(HvLds &S, const HevceImageDesc &im, const HvCu cu) {
+    const int tid = hv_tid();
     HvLds::Level &L = S.lv[cu.lvl];
-    HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
-    HvGLev glev = (HvGLev)scr;
-    HV_GLOBAL u16 *gtok = (HV_GLOBAL u16 *)(scr + HV_TL * 1024 * 3);
-    const int ntrials = (n == 8) ? 71 : 70;
-    const HvCnt cn = { (HV_LDSP u8 *)&S.shdr[0][0], 0 };
     HV_PROF_T0();
-    /* candidates start from the CU's entry snapshot  [ref :1423-1424] */
     for (int k = tid; k < HEVCE_NCTXP * HV_TL; k += HV_NTHREADS) L.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[cu.lvl][k / HV_TL];
-    if (tid < ntrials) L.tregs[tid] = S.ent[cu.lvl];
-
-    if (n >= 16) { BLOCK_SYNC(); return; }                      /* binarised by the job wavefronts in a later round (hv_bin_own) */
-
-    /* ---------------- binarisation: one work item per slot of every candidate (data-parallel) ----------------
-       [ref :1434-1435, 1470-1471, 1540-1541 call the syntax writers per candidate; here only their bins are formed]
-       slot f of candidate t: f = 0 CU header; then per transform block (1 for candidates 0..34, 4 otherwise) a header slot
-       followed by its 4x4 groups from the highest scan index down -- the order the engine consumes them.  Work items are
-       dense and grouped by kind so that the threads of a wavefront execute the same binarisation path. */
-    if (n == 8) {
-        /* candidates 0..69 were binarised by the wavefronts that ran their block jobs (hv_bin_own8); left is candidate 70,
-           the outcome of the NxN chain: four groups (levels in LDS), four block headers, one CU header -- on three wavefronts */
-        const int w = tid - 320;
-        if (w >= 0 && w < 4) hv_bin_group_nxn(S, L, cu, gtok, cn, w);
-        if (w >= 64 && w < 68) hv_bin_tu_header(S, L, cu, gtok, cn, 70, w - 64);
-        if (w == 128) hv_bin_cu_header(S, L, cu, gtok, cn, 70);
-        HV_PROF3L(0);
-    } else {
-        const int ncg_cu = (n >> 2) * (n >> 2);
-        for (int i0 = 0; i0 < 70 * ncg_cu; i0 += HV_NTHREADS) hv_bin_group(S, L, cu, gtok, glev, cn, i0 + tid, i0 + tid < 70 * ncg_cu);
-        HV_PROF3L(0);
-        for (int item = tid; item < 35 * 5; item += HV_NTHREADS)
-            hv_bin_tu_header(S, L, cu, gtok, cn, item < 35 ? item : 35 + ((item - 35) >> 2), item < 35 ? 0 : ((item - 35) & 3));
-        for (int t = tid; t < 70; t += HV_NTHREADS) hv_bin_cu_header(S, L, cu, gtok, cn, t);
-    }
+    if (tid < 70) L.tregs[tid] = S.ent[cu.lvl];
     BLOCK_SYNC();
-    HV_PROF3L(1);
-    /* ---------------- link: per candidate the list of its non-empty slots; the engine walks it ---------------- */
-    for (int t = (n == 8 ? 70 + tid : tid); t < ntrials; t += HV_NTHREADS) hv_build_slist(S, L, cn, n, cu.lvl, t);   /* 8x8: 0..69 are done */
-    if (tid == 0 && n == 8) S.l0_active = 71;                   /* see hv_engine_phase */
-    BLOCK_SYNC();
-    HV_PROF3L(3);
     HV_PROF(S, cu.lvl, 5);
 }
 
@@ -1723,6 +1689,15 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     HV_GLOBAL u8 *s0 = hv_level_scratch(im, 0), *s1 = hv_level_scratch(im, 1), *s2 = hv_level_scratch(im, 2);
     if (wv == 0) {
         hv_job_nxn(wave, lane, q, c8);                          /* clears S.nxn_busy shortly before its end */
+        /* its outcome is candidate 70: four groups (levels in LDS), four block headers, one CU header, the slot list */
+        HvLds::Level &L0 = S.lv[0];
+        HV_GLOBAL u16 *gtok0 = (HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3);
+        const HvCnt cn = { (HV_LDSP u8 *)&S.ws[0] + 4096, 70 };
+        if (lane < 4) hv_bin_group_nxn(S, L0, c8, gtok0, cn, lane);
+        else if (lane < 8) hv_bin_tu_header(S, L0, c8, gtok0, cn, 70, lane - 4);
+        else if (lane == 8) hv_bin_cu_header(S, L0, c8, gtok0, cn, 70);
+        WAVE_SYNC();
+        if (lane == 0) hv_build_slist(S, L0, cn, 8, 0, 70);
         return;
     }
     if (wv == 4) return;                                         /* shares its SIMD with wavefront 0: stays idle */
@@ -1736,6 +1711,12 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         if (w1 < 5) HV_JOBT(9, hv_job_single<8>(wave, lane, q, c8, 2 * (w1 - 3) + 1, l0, r0));
     }
     hv_bin_own(S, im, c8, w1 < 3 ? 35 + 16 * w1 : 16 * (w1 - 3), hv_min(16, (w1 < 3 ? 70 : 35) - (w1 < 3 ? 35 + 16 * w1 : 16 * (w1 - 3))));
+    {   /* the 8x8 candidates' engines start from the CU's entry snapshot  [ref :1423-1424] */
+        HvLds::Level &L0 = S.lv[0];
+        const int t6 = w1 * 64 + lane;
+        for (int k = t6; k < HEVCE_NCTXP * HV_TL; k += 384) L0.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[0][k / HV_TL];
+        if (t6 < 71) L0.tregs[t6] = S.ent[0];
+    }
     if (m == 0) {
         /* 16x16: 5 chains (8 modes each) on slots 0..4, 9 single TUs (4 modes each): one each on slots 0..4, four on slot 5 */
         if (w1 < 5) { HV_JOBT(10, hv_job_chain<8>(wave, lane, q, c16, w1, l1, r1)); HV_JOBT(11, hv_job_single<16>(wave, lane, q, c16, w1, l1, r1)); }
@@ -1968,9 +1949,8 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     hv_jobs_phase(S, im, cu, c16, c32, k, m);
                     BLOCK_SYNC();                                /* the NxN job borrows the 8x8 level's context columns */
                     HV_PROF(S, 0, 0);
-                    hv_prepare_streams(S, im, cu);
-                    if (m == 0) hv_prepare_streams(S, im, c16);
-                    if (k == 1 && m == 2) hv_prepare_streams(S, im, c32);     /* its jobs ran in five phases up to this one */
+                    if (m == 0) hv_level_contexts(S, im, c16);
+                    if (k == 1 && m == 2) hv_level_contexts(S, im, c32);     /* its jobs ran in five phases up to this one */
                     hv_engine_phase(S, im, 1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0), 0);
                 }
                 hv_decide_cu(S, im, cu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr);
