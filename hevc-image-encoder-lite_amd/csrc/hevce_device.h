@@ -193,6 +193,9 @@ struct alignas(16) HvLds {
     u8    nxn_line[35][16];                                 /* per mode: angular reference line r(-4..9) */
     u8    nxn_bord[20];                                     /* raw reference samples of the current 4x4: corner, left[8], above[8] */
     int   nxn_modes[4];
+    alignas(16) u16 nxn_sink[35][96];                       /* finished-byte records of the chain's engines (a 4x4 block: < 80 bytes) */
+    int   nxn_ntok[35];                                     /* tokens per mode of the current 4x4 block */
+    int   c70_len;                                          /* tokens of candidate 70's stream so far */
     u8    nxn_ctx[HEVCE_NCTXP][HV_TL];                      /* context columns of the NxN chain's 35 modes (fresh per 4x4 block) */
     /* control */
     int winner, split_sse;
@@ -1361,12 +1364,13 @@ static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int 
 }
 
 /* NxN job (8x8 CU only): per 4x4 sub-block choose the mode with a fresh coder and fresh contexts  [ref :1499-1528] */
-static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
+static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c70) {
     HvLds &S = HV_S;
     HvLds::Level &L = S.lv[0];
     q = hv_uni(q); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x);
     int total = 0;
     HV_PROF2_T0();
+    if (lane == 0) S.c70_len = 16;
     for (int s = 0; s < 4; s++) {
         int l, lb, a, ar;
         hv_sub_avail(s, cu.L, cu.LB, cu.A, cu.AR, l, lb, a, ar);
@@ -1424,10 +1428,9 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
             /* last block, only its engine to go: tell the candidates riding in the other wavefronts to wind up, so that they are
                at the workgroup barrier when this wavefront gets there */
             if (s == 3 && lane == 0) hv_flag_clear(&S.nxn_busy);
-            /* finished bytes are recorded over the tokens already consumed: record i is written no earlier than token i is
-               processed, and tokens are fetched at least eight ahead */
-            hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb, tk);
-            hv_cod_replay(c, (const HV_LDSP HvChunk *)tk);
+            hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb, (HV_LDSP u16 *)S.nxn_sink[lane]);
+            hv_cod_replay(c, (const HV_LDSP HvChunk *)S.nxn_sink[lane]);
+            S.nxn_ntok[lane] = na + nb;
             cost = hv_rdcost(q, S.nxn_sse[lane], hv_cod_bits(c));
             idx = lane;
         }
@@ -1446,10 +1449,41 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu) {
             L.tinfo[70][s].last = S.nxn_last[w]; L.tinfo[70][s].cbf = S.nxn_sig[w]; L.tinfo[70][s].cgsig = (u64)(S.nxn_sig[w] ? 1 : 0);
         }
         total += S.nxn_sse[w];
+        /* candidate 70 = the four winners: its token stream in HBM is [CU header, 16 tokens reserved][per block: cbf_luma,
+           then -- if the block has levels -- exactly the winner's tokens of above], contiguous, no slot padding */
+        {
+            const int off = S.c70_len, cbf = S.nxn_sig[w], n = cbf ? S.nxn_ntok[w] : 0;
+            const HV_LDSP u16 *src = (const HV_LDSP u16 *)S.nxn_tok[w] + HV_SLOT_TOK0;
+            if (lane == 0) c70[off] = (u16)HV_CT(CX_YCBF, cbf);
+            if (lane < n) c70[off + 1 + lane] = src[lane];
+            if (lane + 64 < n) c70[off + 65 + lane] = src[lane + 64];
+            WAVE_SYNC();
+            if (lane == 0) S.c70_len = off + 1 + n;
+        }
         WAVE_SYNC();
         HV_PROF2(S, 3);
     }
-    if (lane == 0) L.tsse[70] = total;
+    if (lane == 0) {
+        L.tsse[70] = total;
+        /* CU header of candidate 70 (part_mode NxN, the four modes)  [ref :1531-1538], padded to its 16 reserved tokens; the
+           stream padded to whole chunks; one list entry covering it all (it runs on across the candidate's slot area) */
+        const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
+        HvModes pm;
+        for (int s4 = 0; s4 < 4; s4++) pm.mode[s4] = S.nxn_modes[s4];
+        pm.left[0] = L.ml; pm.above[0] = L.ma;
+        pm.left[1] = pm.mode[0];  pm.above[1] = S.map_pm[my - 1][mx + 1];
+        pm.left[2] = S.map_pm[my + 1][mx - 1];  pm.above[2] = pm.mode[0];
+        pm.left[3] = pm.mode[2];  pm.above[3] = pm.mode[1];
+        HvTokW<HV_GLOBAL u16 *> wh = { c70 - HV_SLOT_TOK0, 0 };
+        const int nh = hv_tokenize_cu(wh, 8, 3, 2, L.split_inc, pm);
+        for (int k = nh; k < 16; k++) c70[k] = (u16)HV_TOK_NOP;
+        const int len = S.c70_len;
+        for (int k = len; k < ((len + 7) & ~7); k++) c70[k] = (u16)HV_TOK_NOP;
+        S.slist0[70][0] = (u16)(((len + 7) >> 3) << 8);          /* slot 0, that many chunks */
+        L.tlen[70] = 1; L.tpos[70] = 0;
+        L.tregs[70] = S.ent[0];
+    }
+    for (int r = lane; r < HEVCE_NCTXP; r += 64) L.tctx[r][70] = S.ent_ctx[0][r];
 }
 /* distortion of the CU as currently reconstructed (the "split into four CUs" alternative)  [ref :1409] */
 static HD void hv_job_sse(HvLds &S, int lane, const HvCu &cu) {
@@ -1688,16 +1722,9 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     k16 = hv_uni(k16); m = hv_uni(m);
     HV_GLOBAL u8 *s0 = hv_level_scratch(im, 0), *s1 = hv_level_scratch(im, 1), *s2 = hv_level_scratch(im, 2);
     if (wv == 0) {
-        hv_job_nxn(wave, lane, q, c8);                          /* clears S.nxn_busy shortly before its end */
-        /* its outcome is candidate 70: four groups (levels in LDS), four block headers, one CU header, the slot list */
-        HvLds::Level &L0 = S.lv[0];
-        HV_GLOBAL u16 *gtok0 = (HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3);
-        const HvCnt cn = { (HV_LDSP u8 *)&S.ws[0] + 4096, 70 };
-        if (lane < 4) hv_bin_group_nxn(S, L0, c8, gtok0, cn, lane);
-        else if (lane < 8) hv_bin_tu_header(S, L0, c8, gtok0, cn, 70, lane - 4);
-        else if (lane == 8) hv_bin_cu_header(S, L0, c8, gtok0, cn, 70);
-        WAVE_SYNC();
-        if (lane == 0) hv_build_slist(S, L0, cn, 8, 0, 70);
+        /* the NxN chain; it also writes the token stream, slot list and engine state of its outcome, candidate 70, and
+           clears S.nxn_busy shortly before its end */
+        hv_job_nxn(wave, lane, q, c8, (HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3) + (size_t)70 * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0);
         return;
     }
     if (wv == 4) return;                                         /* shares its SIMD with wavefront 0: stays idle */
