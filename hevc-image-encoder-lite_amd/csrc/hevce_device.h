@@ -771,17 +771,18 @@ static HD void hv_engine_prime(const HvLds &S, u8 *cx, const HvChunk &first, HvT
     B.cvl = *B.cp & 0x7f;
 }
 
-/* contiguous stream of n tokens at sp (16-byte chunks; the NxN sub-search's streams in LDS) */
+/* contiguous stream of n tokens at sp (16-byte chunks; the NxN sub-search's streams in LDS), followed by at least 8 no-op
+   tokens so that the last chunk needs no range checks */
 template <typename ChunkPtr, typename SinkP>
 static HD void hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int n, SinkP sink) {
     if (n <= 0) return;
     HvChunk nxt = sp[0];
     HvTokA A; HvTokB B;
-    hv_engine_prime(S, cx, nxt, A, B, n);
+    hv_engine_prime(S, cx, nxt, A, B, 8);
     for (int base = 0; base < n; base += 8) {
         const HvChunk cur = nxt;
         nxt = sp[(base >> 3) + 1];                                /* requested eight tokens ahead of its first use */
-        hv_engine_chunk(S, c, cx, cur, nxt, A, B, n - base, sink);
+        hv_engine_chunk(S, c, cx, cur, nxt, A, B, 16, sink);
     }
 }
 
@@ -1424,6 +1425,8 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
             HvCg g;
             hv_cg_load(S, g, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0), 1);
             const int nb = hv_cg_emit(S, wb, g, 0);
+#pragma unroll
+            for (int i = 0; i < 8; i++) tk[HV_SLOT_TOK0 + na + nb + i] = (u16)HV_TOK_NOP;
             HV_PROF2(S, 1);
             /* last block, only its engine to go: tell the candidates riding in the other wavefronts to wind up, so that they are
                at the workgroup barrier when this wavefront gets there */
