@@ -697,14 +697,13 @@ static HD int hv_chunk_get(const HvChunk &c, int i) {
     const unsigned d = (i & 2) ? hi : lo;
     return (int)((d >> ((i & 1) << 4)) & 0xffffu);
 }
-/* The arithmetic engine of one candidate over tokens [i0, i1) of its linked stream (chunk pointer, 16-byte aligned);
-   resumable: the coder registers and the position are all the state there is.
-   cx = &S.tctx[0][trial].  All lanes of a wavefront run this loop in lockstep; one iteration = one token through the
-   same straight-line code for context-coded bins and bypass chunks; the next 8-token chunk is requested 8 tokens ahead.
+/* The arithmetic engine of a candidate  [ref CABACputBin / CABACputBins :899-933]: resumable -- the coder registers and the
+   position in the token stream are all the state there is.  cx = the candidate's context column (&tctx[0][candidate]).
+   All lanes of a wavefront run the loop in lockstep; one iteration = one token through the same straight-line code for
+   context-coded bins and bypass chunks; 16-byte chunks of tokens are requested eight tokens ahead.
    Pruning (exact): a candidate's cost w1*sse + w2*bits only grows while it is being encoded, so once its partial cost
    exceeds the cost of a candidate that has COMPLETED (or of the split alternative, known beforehand) it cannot be the
-   arg-min, which is the LAST candidate of MINIMAL cost (ref :1440 adopts on >=).  Returns 1 when abandoned.
-   [ref CABACputBin / CABACputBins :899-933] */
+   arg-min, which is the LAST candidate of MINIMAL cost (ref :1440 adopts on >=). */
 /* one token through the coder: context-coded bin or bypass chunk, same straight-line code.
    cv = the token's context byte, ct = S.ctab[cv] -- both fetched while the PREVIOUS token was processed, so that no
    memory access sits on the range -> range dependency chain (the LPS range is a byte of ct picked by the range quarter,
@@ -1511,12 +1510,13 @@ static HD void hv_commit_bin(HvLds &S, int ctx, int bin) {
 }
 
 /* --------------------------------------------------------------------------------------------- */
-/* evaluation of one CU  [ref HEVCe.c:1350-1560] in three steps:                                    */
-/*   hv_prepare_cu : at the CU's ENTRY (its entry coder state and outside neighbours are all the     */
-/*                   non-split candidates depend on): TU jobs, binarisation, linking, engine state   */
-/*   hv_engine_phase: arithmetic engines; 8x8 candidates run to completion, 16x16 / 32x32 candidates */
-/*                   advance by a quota of tokens, i.e. are time-sliced over their children's phases */
-/*   hv_decide_cu  : split alternative, arg-min (last of minimum), commit                            */
+/* evaluation of the CUs  [ref HEVCe.c:1350-1560]: one round of three phases per 8x8 CU                */
+/*   hv_jobs_phase  : wavefront 0 walks the NxN chain; the job wavefronts run the block jobs of the 8x8 */
+/*                    CU and of the enclosing CUs, binarise what they produced, and let prepared        */
+/*                    candidates of the enclosing CUs ride in their idle time                           */
+/*   hv_engine_phase: arithmetic engines; the 8x8 candidates run to completion, 16x16 / 32x32           */
+/*                    candidates ride along                                                             */
+/*   hv_decide_cu   : split alternative, arg-min (last of minimum), commit                              */
 /* --------------------------------------------------------------------------------------------- */
 static HD HV_GLOBAL u8 *hv_level_scratch(const HevceImageDesc &im, int lvl) { return (HV_GLOBAL u8 *)(im.scratch + (size_t)lvl * HEVCE_SCRATCH_LEVEL_BYTES); }
 static HD int hv_trial_slots(int n, int t) { const int tn = t < 35 ? n : (n >> 1); return 1 + (t < 35 ? 1 : 4) * (1 + (tn >> 2) * (tn >> 2)); }
@@ -1709,7 +1709,7 @@ static HD void hv_bin_own(HvLds &S, const HevceImageDesc &im, const HvCu cu, int
 
 /* TU-job phase of the 8x8 CU number m (0..3) of the 16x16 CU number k16 (0..3).  Wavefront 0 walks the NxN chain, the
    longest job by far; wavefront 4, on the same SIMD, stays idle.  The other six ("job wavefronts", work slots 0..5):
-     1. the 8x8 CU's eight block jobs, then the binarisation of the candidates they produced (hv_bin_own8);
+     1. the 8x8 CU's eight block jobs, then the binarisation of the candidates they produced (hv_bin_own);
      2. the jobs of the enclosing CUs, which only depend on samples outside those CUs: all 14 jobs of the 16x16 CU during
         its first child (m == 0), the 27 jobs of the 32x32 CU one per slot in rounds (0,1) (0,2) (0,3) (1,1) (1,2);
      3. in the time the NxN chain still takes, the prepared candidates of the enclosing CUs ride on.
