@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU: many small pictures (random sizes, content classes, qpd6) in batches through the
+C ABI, every stream and reconstruction compared with the oracle (CPU restatement; test infrastructure).  The kernel's
+wavefronts hand work to each other through LDS flags and idle-time riding, i.e. its timing varies from launch to launch:
+this sweep is there to catch what a fixed set of goldens cannot.  usage: gpu_stress.py [n_pictures] [seed] [repeats]"""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import hevce_pkg, hevce_workload as wl, orc
+hevce = hevce_pkg.load()
+
+
+def sweep(n, seed, repeats):
+    rng = np.random.default_rng(seed)
+    imgs, qs = [], []
+    for i in range(n):
+        h, w = int(rng.integers(1, 161)), int(rng.integers(1, 225))
+        kind = i % 6
+        if kind == 0: img = wl.gen_g2(h, w, int(rng.choice([1, 4, 16, 48])), seed=int(rng.integers(1, 2**31)))
+        elif kind == 1: img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == 2: img = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+        elif kind == 3: img = ((np.add.outer(np.arange(h) * int(rng.integers(0, 5)), np.arange(w) * int(rng.integers(0, 5))) + rng.integers(0, 6, (h, w))) & 255).astype(np.uint8)
+        elif kind == 4: img = (rng.integers(0, 2, (h, w), dtype=np.uint8) * 255)
+        else: img = np.clip(np.kron(rng.integers(0, 256, ((h + 7) // 8, (w + 7) // 8)), np.ones((8, 8)))[:h, :w] + rng.integers(-3, 4, (h, w)), 0, 255).astype(np.uint8)
+        imgs.append(np.ascontiguousarray(img)); qs.append(int(rng.integers(0, 5)))
+    t = time.perf_counter()
+    want = [orc.encode(im, q) for im, q in zip(imgs, qs)]
+    t_cpu = time.perf_counter() - t
+    bad = []
+    t = time.perf_counter()
+    for r in range(repeats):
+        got = hevce.encode_batch(imgs, qs)
+        for i, ((s, rc), (ws, wrc)) in enumerate(zip(got, want)):
+            if s != ws or not np.array_equal(rc, wrc): bad.append((r, i, imgs[i].shape, qs[i]))
+    t_gpu = time.perf_counter() - t
+    return {"pictures": n, "seed": seed, "repeats": repeats, "mismatches": len(bad), "first": bad[:5],
+            "oracle_s": round(t_cpu, 1), "gpu_s": round(t_gpu, 2),
+            "ctus": int(sum(((im.shape[0] + 31) // 32) * ((im.shape[1] + 31) // 32) for im in imgs))}
+
+
+if __name__ == "__main__":
+    res = sweep(int(sys.argv[1]) if len(sys.argv) > 1 else 96, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+                int(sys.argv[3]) if len(sys.argv) > 3 else 3)
+    print(json.dumps(res))
+    sys.exit(1 if res["mismatches"] else 0)
