@@ -1906,6 +1906,9 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     if (tid == 0) S.trace = im.trace;
     if (tid < 24) (&S.prof[0][0])[tid] = 0;
     if (tid < 32) S.prof2[tid] = 0;
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+    const unsigned long long prof_start_ = __builtin_amdgcn_s_memtime();
+#endif
     BLOCK_SYNC();
     HV_TRACE(S, 0, 1);
     hv_init_tables(S, q, tid);
@@ -2008,5 +2011,6 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     if (im.trace && tid < 24) { ((unsigned long long *)im.trace)[tid] = (&S.prof[0][0])[tid]; }
     if (im.trace && tid < 32) { ((unsigned long long *)im.trace)[24 + tid] = S.prof2[tid]; }
+    if (im.trace && tid == 0) ((unsigned long long *)im.trace)[56] = __builtin_amdgcn_s_memtime() - prof_start_;   /* whole picture */
 #endif
 }

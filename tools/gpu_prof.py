@@ -16,7 +16,8 @@ with hevce.Job([img.shape], 2) as job:
 prof = tr[:48].view(np.uint64).reshape(3, 8)
 nctu = (hevce.pad32(h) // 32) * (hevce.pad32(w) // 32)
 tot = prof.sum()
-print(f"{w}x{h}: kernel {tm['kernel_ms']:.1f} ms, {tm['kernel_ms']*1e3/nctu:.0f} us/CTU, stamped cycles {tot/1e6:.1f} M ({tot/nctu/1e3:.0f} k/CTU)")
+whole = int(tr[112:114].view(np.uint64)[0])
+print(f"{w}x{h}: kernel {tm['kernel_ms']:.1f} ms, {tm['kernel_ms']*1e3/nctu:.0f} us/CTU, WHOLE KERNEL {whole/nctu/1e3:.0f} k cycles/CTU (clock {whole/tm['kernel_ms']/1e6:.2f} GHz), stamped {tot/nctu/1e3:.0f} k/CTU")
 names = ["TU jobs", "ctx init", "engine", "arg-min", "commit", "binarise"]
 p2 = tr[48:80].view(np.uint64)
 for lvl, nm in enumerate(("8x8", "16x16", "32x32")):
