@@ -177,6 +177,7 @@ struct alignas(16) HvLds {
         HevceCoderRegs tregs[HV_TL];
         int tcost[HV_TL], tsse[HV_TL];
         int tlen[HV_TL], tpos[HV_TL];                       /* list entries; position (entry | chunk << 8), -1 = finished / abandoned */
+        int tnlog[HV_TL];                                   /* finished-byte records in the candidate's sink so far */
         HvTuInfo tinfo[HV_TL][4];
         u8  tdead[HV_TL];                                   /* abandoned: partial cost already above best_cost */
         int best_cost;                                      /* lowest cost of a COMPLETED candidate (pruning bound) */
@@ -201,6 +202,10 @@ struct alignas(16) HvLds {
     int winner, split_sse;
     int l0_active;                                          /* 8x8 candidates whose engines still run in this engine phase */
     int nxn_busy;                                           /* 1 while wavefront 0 walks the NxN chain of the current 8x8 CU */
+    /* device-side byte emission: the CTU's finished bytes are collected in coding order (a stack: a CU that ends up unsplit
+       rewinds to its mark and pushes its winner's); the previous CTU's are turned into stream bytes by wavefront 4 meanwhile */
+    int em_pos, em_mark[3], em_cnt[2];
+    int em_held, em_pending, em_zeros, em_n;                /* the emitting coder's byte state  [ref :797-806, 821-832, 859-879] */
     unsigned long long prof[3][8];
     unsigned long long prof2[32];                           /* HEVCE_PROF: inside the NxN job (tu jobs, tokenise, engine, select) */
     int *trace;
@@ -348,19 +353,20 @@ static HD void hv_cod_byte(HvCod &c, int lead, int on) {
         for (; c.nbytes > 1; c.nbytes--) hv_cod_out(c, fill);
     }
 }
-template <typename ChunkP> static HD void hv_cod_replay(HvCod &c, ChunkP sink8) {     /* sink as 16-byte chunks of eight records */
-    const int n = c.nev;
+/* sink8 = the sink as 16-byte chunks of eight records; the c.nev records to account start at record `first` of it */
+template <typename ChunkP> static HD void hv_cod_replay(HvCod &c, ChunkP sink8, int first = 0) {
+    const int lo = first, hi = first + c.nev;
     c.nev = 0; c.zf = 0;
-    HvChunk nxt = sink8[0];
-    for (int base = 0; base < n; base += 8) {
+    HvChunk nxt = sink8[lo >> 3];
+    for (int base = lo & ~7; base < hi; base += 8) {
         const HvChunk ch = nxt;
         nxt = sink8[(base >> 3) + 1];                             /* the sink may be in HBM: fetch ahead */
 #pragma unroll
-        for (int j = 0; j < 8; j++) hv_cod_byte(c, (int)((ch[j >> 1] >> ((j & 1) << 4)) & 0xffffu), base + j < n);
+        for (int j = 0; j < 8; j++) hv_cod_byte(c, (int)((ch[j >> 1] >> ((j & 1) << 4)) & 0xffffu), base + j >= lo && base + j < hi);
     }
 }
 /* context-coded bin; cx points at this trial's context byte  [ref :914-933] */
-static HD void hv_bin(const HvLds &S, HvCod &c, u8 *cx, int bin) {
+static HD void hv_bin(const HvLds &S, HvCod &c, u8 *cx, int bin, HV_GLOBAL u16 *log = nullptr, int *nlog = nullptr) {
     const int v = *cx, st = v >> 1, mps = v & 1;
     const int lps = (int)((S.lps4[st] >> (((c.range >> 6) & 3) << 3)) & 0xff);
     c.range -= lps;
@@ -374,6 +380,7 @@ static HD void hv_bin(const HvLds &S, HvCod &c, u8 *cx, int bin) {
         if (st < 62) *cx = (u8)(v + 2);
         if (c.range < 256) { c.low <<= 1; c.range <<= 1; c.nbits--; }
     }
+    if (log && c.nbits < 12) log[(*nlog)++] = (u16)(c.low >> (24 - c.nbits));   /* the byte hv_cod_carry is about to take */
     hv_cod_carry(c);
 }
 static HD void hv_bypass(HvCod &c, int bins, int len) {                                                    /* [ref :899-911] */
@@ -386,10 +393,11 @@ static HD void hv_bypass(HvCod &c, int bins, int len) {                         
         hv_cod_carry(c);
     }
 }
-static HD void hv_terminate(HvCod &c, int bin) {                                                           /* [ref :882-896] */
+static HD void hv_terminate(HvCod &c, int bin, HV_GLOBAL u16 *log = nullptr, int *nlog = nullptr) {              /* [ref :882-896] */
     c.range -= 2;
     if (bin) { c.low = (c.low + (unsigned)c.range) << 7; c.range = 256; c.nbits -= 7; }
     else if (c.range < 256) { c.low <<= 1; c.range <<= 1; c.nbits--; }
+    if (log && c.nbits < 12) log[(*nlog)++] = (u16)(c.low >> (24 - c.nbits));
     hv_cod_carry(c);
 }
 
@@ -1482,7 +1490,7 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
         const int len = S.c70_len;
         for (int k = len; k < ((len + 7) & ~7); k++) c70[k] = (u16)HV_TOK_NOP;
         S.slist0[70][0] = (u16)(((len + 7) >> 3) << 8);          /* slot 0, that many chunks */
-        L.tlen[70] = 1; L.tpos[70] = 0;
+        L.tlen[70] = 1; L.tpos[70] = 0; L.tnlog[70] = 0;
         L.tregs[70] = S.ent[0];
     }
     for (int r = lane; r < HEVCE_NCTXP; r += 64) L.tctx[r][70] = S.ent_ctx[0][r];
@@ -1500,11 +1508,11 @@ static HD void hv_job_sse(HvLds &S, int lane, const HvCu &cu) {
 }
 
 /* one context-coded bin on the committed coder (split_cu_flag = 1 of a parent)  [ref :1404] */
-static HD void hv_commit_bin(HvLds &S, int ctx, int bin) {
+static HD void hv_commit_bin(HvLds &S, const HevceImageDesc &im, int ctu, int ctx, int bin) {
     HvCod c;
     hv_cod_load(c, S.com);
     u8 tmp = S.com_ctx[ctx];
-    hv_bin(S, c, &tmp, bin);
+    hv_bin(S, c, &tmp, bin, im.leadlog ? (HV_GLOBAL u16 *)im.leadlog + (ctu & 1) * HEVCE_LEADLOG_WORDS : nullptr, &S.em_pos);
     S.com_ctx[ctx] = tmp;
     hv_cod_store(S.com, c);
 }
@@ -1617,7 +1625,7 @@ static HD void hv_build_slist(HvLds &S, HvLds::Level &L, const HvCnt &cn, int n,
         ls[k] = (u16)(f | (ch << 8));
         k += (ch != 0);
     }
-    L.tlen[t] = k; L.tpos[t] = 0;
+    L.tlen[t] = k; L.tpos[t] = 0; L.tnlog[t] = 0;
 }
 
 /* candidates of a 16x16 / 32x32 CU start from its entry snapshot  [ref :1423-1424]: context columns and coder registers
@@ -1655,9 +1663,11 @@ static HD void hv_run_engines(HvLds &S, const HevceImageDesc &im, int mask, int 
             HV_GLOBAL u16 *sink = (HV_GLOBAL u16 *)(hv_level_scratch(im, lvl) + HV_TL * 1024 * 3 + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT * 2) + (size_t)t * HEVCE_SINK_WORDS;
             int dead = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0) > hv_peek(&L.best_cost);
             hv_cod_span(c);
+            const int nlog = L.tnlog[t];                          /* the records stay: they are the candidate's bytes, should it win */
             dead = hv_engine_slots(S, c, &L.tctx[0][t], slots, hv_slist(S, lvl, t), nlist, k, ci, dead, shared,
-                                   shared && lvl == 0, q, L.tsse[t], bits0, &L.best_cost, sink);
-            hv_cod_replay(c, (const HV_GLOBAL HvChunk *)sink);
+                                   shared && lvl == 0, q, L.tsse[t], bits0, &L.best_cost, sink + nlog);
+            L.tnlog[t] = nlog + c.nev;
+            hv_cod_replay(c, (const HV_GLOBAL HvChunk *)sink, nlog);
             hv_cod_store(L.tregs[t], c);
             if (dead) { L.tdead[t] = 1; L.tcost[t] = HV_I32MAX; L.tpos[t] = -1; }
             else if (k >= nlist) {
@@ -1707,6 +1717,48 @@ static HD void hv_bin_own(HvLds &S, const HevceImageDesc &im, const HvCu cu, int
     for (int j = lane; j < tc; j += 64) hv_build_slist(S, L, cn, cu.n, cu.lvl, tb + j);
 }
 
+/* Device-side byte emission  [ref CABACput :821-832, CABACupdate :859-879, CABACfinish :840-856].
+   The finished bytes of a CTU -- 9-bit values, carry + byte, in coding order -- become stream bytes: pending byte, runs of
+   0xff waiting for a carry, start-code emulation prevention.  One lane; the state lives in LDS between calls. */
+struct HvEmit { int held, pending, zeros, n; HV_GLOBAL u8 *out; };
+static HD void hv_em_put(HvEmit &e, int byte) {
+    byte &= 0xff;
+    if (e.zeros >= 2 && byte <= 3) { e.out[e.n++] = 3; e.zeros = 0; }
+    e.out[e.n++] = (u8)byte;
+    e.zeros = byte ? 0 : e.zeros + 1;
+}
+static HD HvEmit hv_em_load(const HvLds &S, const HevceImageDesc &im) { HvEmit e = { S.em_held, S.em_pending, S.em_zeros, S.em_n, (HV_GLOBAL u8 *)im.payload }; return e; }
+static HD void hv_em_store(HvLds &S, const HvEmit &e) { S.em_held = e.held; S.em_pending = e.pending; S.em_zeros = e.zeros; S.em_n = e.n; }
+static HD void hv_emit_ctu(HvLds &S, const HevceImageDesc &im, int which) {
+    const HV_GLOBAL u16 *log = (const HV_GLOBAL u16 *)im.leadlog + which * HEVCE_LEADLOG_WORDS;
+    const int n = S.em_cnt[which];
+    HvEmit e = hv_em_load(S, im);
+    for (int i = 0; i < n; i++) {
+        const int lead = log[i & (HEVCE_LEADLOG_WORDS - 1)];
+        if (lead == 0xff) { e.pending++; continue; }
+        if (e.pending > 0) {
+            const int c = lead >> 8, fill = (0xff + c) & 0xff;
+            hv_em_put(e, e.held + c);
+            e.held = lead & 0xff;
+            for (; e.pending > 1; e.pending--) hv_em_put(e, fill);
+        } else { e.pending = 1; e.held = lead; }                 /* first byte ever: stored unmasked, as the reference does */
+    }
+    hv_em_store(S, e);
+}
+static HD void hv_emit_finish(HvLds &S, const HevceImageDesc &im) {
+    HvEmit e = hv_em_load(S, im);
+    unsigned low = S.com.low;
+    const int bits = S.com.nbits;
+    int fill = 0;
+    if ((low >> (32 - bits)) > 0) { hv_em_put(e, e.held + 1); low -= 1u << (32 - bits); }
+    else { if (e.pending > 0) hv_em_put(e, e.held); fill = 0xff; }
+    for (; e.pending > 1; e.pending--) hv_em_put(e, fill);
+    const int tail = (int)((low >> 8) << bits);
+    hv_em_put(e, tail >> 16); hv_em_put(e, tail >> 8); hv_em_put(e, tail);
+    hv_em_store(S, e);
+    *im.payload_len = e.n;
+}
+
 /* TU-job phase of the 8x8 CU number m (0..3) of the 16x16 CU number k16 (0..3).  Wavefront 0 walks the NxN chain, the
    longest job by far; wavefront 4, on the same SIMD, stays idle.  The other six ("job wavefronts", work slots 0..5):
      1. the 8x8 CU's eight block jobs, then the binarisation of the candidates they produced (hv_bin_own);
@@ -1719,7 +1771,7 @@ static HD void hv_bin_own(HvLds &S, const HevceImageDesc &im, const HvCu cu, int
 #else
 #define HV_JOBT(slot, call) call
 #endif
-static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m) {
+static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m, int ctu) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
     const int wv = hv_uni(wave);
     k16 = hv_uni(k16); m = hv_uni(m);
@@ -1730,7 +1782,11 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         hv_job_nxn(wave, lane, q, c8, (HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3) + (size_t)70 * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0);
         return;
     }
-    if (wv == 4) return;                                         /* shares its SIMD with wavefront 0: stays idle */
+    if (wv == 4) {                                               /* shares its SIMD with wavefront 0: idle, except that once per CTU it
+                                                                    turns the previous CTU's finished bytes into stream bytes */
+        if (im.payload && k16 == 0 && m == 0 && ctu > 0 && lane == 0) hv_emit_ctu(S, im, (ctu - 1) & 1);
+        return;
+    }
     const int w1 = wv < 4 ? wv - 1 : wv - 2;                     /* work slot 0..5 */
     HvGLev l0 = (HvGLev)s0, l1 = (HvGLev)s1, l2 = (HvGLev)s2;
     HvGRec r0 = (HvGRec)(s0 + HV_TL * 1024 * 2), r1 = (HvGRec)(s1 + HV_TL * 1024 * 2), r2 = (HvGRec)(s2 + HV_TL * 1024 * 2);
@@ -1767,7 +1823,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     hv_run_engines(S, im, (m >= 2 ? 2 : 0) | (k16 >= 2 ? 4 : 0), &S.nxn_busy, 6, w1);
 }
 
-static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HevceRecord *rec, int32_t *dump) {
+static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, HevceRecord *rec, int32_t *dump) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, n = cu.n;
     HvLds::Level &L = S.lv[cu.lvl];
     HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
@@ -1818,6 +1874,16 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, H
     if (w < 0) return;                                          /* the four sub-CUs stay */
 
     /* ---------------- commit the winner: coder, contexts, reconstruction, maps, record ---------------- */
+    if (im.leadlog) {
+        /* its finished bytes take the place of whatever this CU had pushed so far (the split flag and the sub-CUs' bytes of a
+           16x16 / 32x32 CU that ends up unsplit) */
+        const int base = (n > 8) ? S.em_mark[cu.lvl] : S.em_pos, cnt = L.tnlog[w];
+        HV_GLOBAL u16 *log = (HV_GLOBAL u16 *)im.leadlog + (ctu & 1) * HEVCE_LEADLOG_WORDS;
+        const HV_GLOBAL u16 *src = (const HV_GLOBAL u16 *)(scr + HV_TL * 1024 * 3 + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT * 2) + (size_t)w * HEVCE_SINK_WORDS;
+        for (int i = tid; i < cnt; i += HV_NTHREADS) log[(base + i) & (HEVCE_LEADLOG_WORDS - 1)] = src[i];
+        BLOCK_SYNC();
+        if (tid == 0) S.em_pos = base + cnt;
+    }
     if (tid == 0) S.com = L.tregs[w];
     if (tid < HEVCE_NCTXP) S.com_ctx[tid] = L.tctx[tid][w];
     const int kindw = w < 35 ? 0 : (w < 70 ? 1 : 2);
@@ -1879,6 +1945,7 @@ static HD void hv_init_tables(HvLds &S, int q, int tid) {
         const u8 v = (u8)(st >= 64 ? (((st - 64) << 1) | 1) : ((63 - st) << 1));
         S.ctx_fresh[i] = v; S.com_ctx[i] = v;
     }
+    if (tid == 301) { S.em_pos = 0; S.em_cnt[0] = S.em_cnt[1] = 0; S.em_held = 0xff; S.em_pending = 0; S.em_zeros = 0; S.em_n = 0; }
     if (tid == 300) { S.com.range = 510; S.com.low = 0; S.com.nbits = 23; S.com.nbytes = 0; S.com.bufbyte = 0xff; S.com.zeros = 0; S.com.nout = 0; S.com.pad = 0; }
 }
 
@@ -1964,14 +2031,14 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     hv_snapshot(S, 2, tid);
                     hv_level_begin(S, c32);
                     BLOCK_SYNC();
-                    if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + S.lv[2].split_inc, 1);
+                    if (tid == 0) { S.em_mark[2] = S.em_pos; hv_commit_bin(S, im, ctu, CX_SPLIT_CU + S.lv[2].split_inc, 1); }
                     BLOCK_SYNC();
                 }
                 if (step < 20 && m == 0) {                       /* entering a 16x16 CU */
                     hv_snapshot(S, 1, tid);
                     hv_level_begin(S, c16);
                     BLOCK_SYNC();
-                    if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + S.lv[1].split_inc, 1);
+                    if (tid == 0) { S.em_mark[1] = S.em_pos; hv_commit_bin(S, im, ctu, CX_SPLIT_CU + S.lv[1].split_inc, 1); }
                     BLOCK_SYNC();
                 }
                 if (cu.n == 8) {
@@ -1979,22 +2046,23 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     hv_level_begin(S, cu);
                     BLOCK_SYNC();
                     HV_PROF_T0();
-                    hv_jobs_phase(S, im, cu, c16, c32, k, m);
+                    hv_jobs_phase(S, im, cu, c16, c32, k, m, ctu);
                     BLOCK_SYNC();                                /* the NxN job borrows the 8x8 level's context columns */
                     HV_PROF(S, 0, 0);
                     if (m == 0) hv_level_contexts(S, im, c16);
                     if (k == 1 && m == 2) hv_level_contexts(S, im, c32);     /* its jobs ran in five phases up to this one */
                     hv_engine_phase(S, im, 1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0), 0);
                 }
-                hv_decide_cu(S, im, cu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr);
+                hv_decide_cu(S, im, cu, ctu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr);
             }
 
             /* ---- end of CTU: terminate bin, publish reconstruction and line buffers  [ref :1626-1637] ---- */
             if (tid == 0) {
                 HvCod c;
                 hv_cod_load(c, S.com);
-                hv_terminate(c, (y0 + 32 >= H) && (x0 + 32 >= W));
+                hv_terminate(c, (y0 + 32 >= H) && (x0 + 32 >= W), im.leadlog ? (HV_GLOBAL u16 *)im.leadlog + (ctu & 1) * HEVCE_LEADLOG_WORDS : nullptr, &S.em_pos);
                 hv_cod_store(S.com, c);
+                S.em_cnt[ctu & 1] = S.em_pos; S.em_pos = 0;      /* this CTU's bytes are complete: wavefront 4 emits them during the next CTU */
                 if (im.ctu_state) {
                     int32_t *st = im.ctu_state + (size_t)ctu * 8;
                     st[0] = c.range; st[1] = (int32_t)c.low; st[2] = c.nbits; st[3] = c.nbytes; st[4] = c.bufbyte; st[5] = c.zeros;
@@ -2008,6 +2076,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
             BLOCK_SYNC();
         }
     }
+    if (im.payload && tid == 0) { hv_emit_ctu(S, im, (ctu - 1) & 1); hv_emit_finish(S, im); }   /* the last CTU's bytes and the coder's tail */
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     if (im.trace && tid < 24) { ((unsigned long long *)im.trace)[tid] = (&S.prof[0][0])[tid]; }
     if (im.trace && tid < 32) { ((unsigned long long *)im.trace)[24 + tid] = S.prof2[tid]; }

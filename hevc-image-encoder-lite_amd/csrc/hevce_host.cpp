@@ -53,7 +53,8 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 struct Image {
     int h0, w0, H, W, q, nctu;
     size_t off_img, off_rcon, off_rec, off_state, off_scratch;   /* into the device slab */
-    size_t hoff_rec, hoff_state;                                 /* into the pinned host slab */
+    size_t off_payload, off_leadlog, off_plen;                   /* device-side byte emission: slice data, byte log, length */
+    size_t hoff_rec, hoff_state, hoff_plen;                      /* into the pinned host slab */
     const void *ext_img = nullptr;
     std::vector<uint8_t> stream;
     int length = 0;
@@ -69,6 +70,7 @@ struct hevce_job {
     HevceImageDesc *d_desc = nullptr;
     std::vector<HevceImageDesc> h_desc;
     bool desc_dirty = true, launched = false;
+    bool device_emit = true;         /* the kernel emits the slice data itself; HEVCE_HOST_WRITER=1: replay the records on the host instead */
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     float kernel_ms = 0, d2h_ms = 0, writer_ms = 0;
@@ -105,8 +107,12 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
         m.off_rec = d;     d = align256(d + size_t(m.nctu) * HEVCE_REC_BYTES);
         m.off_state = d;   d = align256(d + size_t(m.nctu) * 32);
         m.off_scratch = d; d = align256(d + HEVCE_SCRATCH_BYTES);
+        m.off_payload = d; d = align256(d + size_t(m.nctu) * 3200 + 64);
+        m.off_leadlog = d; d = align256(d + size_t(2) * HEVCE_LEADLOG_WORDS * 2);
+        m.off_plen = d;    d = align256(d + 4);
         m.hoff_rec = h;    h = align256(h + size_t(m.nctu) * HEVCE_REC_BYTES);
         m.hoff_state = h;  h = align256(h + size_t(m.nctu) * 32);
+        m.hoff_plen = h;   h = align256(h + 4);
     }
     j->d_bytes = d; j->h_bytes = h;
     bool ok = hipMalloc((void **)&j->d_slab, d) == hipSuccess
@@ -116,6 +122,7 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
            && hipEventCreate(&j->ev0) == hipSuccess && hipEventCreate(&j->ev1) == hipSuccess && hipEventCreate(&j->ev2) == hipSuccess;
     if (!ok) { fail("hevce_job_create: device allocation failed (%zu bytes HBM, %zu bytes pinned)", d, h); hevce_job_destroy(j); return nullptr; }
     j->stream = j->own_stream;
+    j->device_emit = getenv("HEVCE_HOST_WRITER") == nullptr;
     if (getenv("HEVCE_DUMP")) {
         for (int i = 0; i < n; i++) j->dump_ints += size_t(j->im[i].nctu) * 21 * HEVCE_TRIALS * 16;
         if (hipMalloc((void **)&j->d_dump, j->dump_ints * 4) != hipSuccess) j->d_dump = nullptr;
@@ -183,6 +190,9 @@ int hevce_job_launch(hevce_job *j) {
             d.scratch = j->d_slab + m.off_scratch;
             d.src_h = m.h0; d.src_w = m.w0; d.H = m.H; d.W = m.W; d.qpd6 = m.q; d.status = 0;
             d.trace = j->h_trace ? j->h_trace + 1024 * i : nullptr;
+            d.payload = j->device_emit ? j->d_slab + m.off_payload : nullptr;
+            d.leadlog = j->device_emit ? (uint16_t *)(j->d_slab + m.off_leadlog) : nullptr;
+            d.payload_len = j->device_emit ? (int32_t *)(j->d_slab + m.off_plen) : nullptr;
         }
         HIPCHK(hipMemcpyAsync(j->d_desc, j->h_desc.data(), sizeof(HevceImageDesc) * j->n, hipMemcpyHostToDevice, j->stream));
         j->desc_dirty = false;
@@ -195,6 +205,7 @@ int hevce_job_launch(hevce_job *j) {
         const Image &m = j->im[i];
         HIPCHK(hipMemcpyAsync(j->h_slab + m.hoff_rec, j->d_slab + m.off_rec, size_t(m.nctu) * HEVCE_REC_BYTES, hipMemcpyDeviceToHost, j->stream));
         HIPCHK(hipMemcpyAsync(j->h_slab + m.hoff_state, j->d_slab + m.off_state, size_t(m.nctu) * 32, hipMemcpyDeviceToHost, j->stream));
+        if (j->device_emit) HIPCHK(hipMemcpyAsync(j->h_slab + m.hoff_plen, j->d_slab + m.off_plen, 4, hipMemcpyDeviceToHost, j->stream));
     }
     HIPCHK(hipEventRecord(j->ev2, j->stream));
     j->launched = true;
@@ -209,6 +220,20 @@ int hevce_job_finish(hevce_job *j) {
     HIPCHK(hipEventElapsedTime(&j->kernel_ms, j->ev0, j->ev1));
     HIPCHK(hipEventElapsedTime(&j->d2h_ms, j->ev1, j->ev2));
     const auto t0 = std::chrono::steady_clock::now();
+    if (j->device_emit) {
+        /* the kernel has emitted the slice data; the host only puts the VPS/SPS/PPS/slice header in front  [ref :625-691] */
+        for (int i = 0; i < j->n; i++) {
+            Image &m = j->im[i];
+            const int plen = *(const int32_t *)(j->h_slab + m.hoff_plen);
+            if (plen <= 0 || size_t(plen) > size_t(m.nctu) * 3200 + 64) return fail("image %d: the device emitted %d bytes", i, plen);
+            m.stream.resize((size_t)hevce_stream_bound(m.h0, m.w0));
+            const int hdr = hevce_write_header(m.stream.data(), m.q, m.H, m.W);
+            HIPCHK(hipMemcpy(m.stream.data() + hdr, j->d_slab + m.off_payload, size_t(plen), hipMemcpyDeviceToHost));
+            m.length = hdr + plen;
+        }
+        j->writer_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    }
     /* host stream writer: images are independent, one thread each (bounded by the host's cores) */
     unsigned hw = std::thread::hardware_concurrency();
     if (const char *e = getenv("HEVCE_WRITER_THREADS")) hw = (unsigned)atoi(e);

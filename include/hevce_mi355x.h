@@ -47,11 +47,13 @@ int  hevce_job_upload(hevce_job *job, int i, const unsigned char *img);
 int  hevce_job_set_device_image(hevce_job *job, int i, const void *d_img);
 /* run on this hipStream_t (NULL = the job's own stream) */
 int  hevce_job_set_stream(hevce_job *job, void *hip_stream);
-/* analysis kernel over all images + D2H of the decision records + host stream writer.  0 on success */
+/* analysis kernel over all images (it also emits each image's slice data) + D2H of the decision records and of the
+   slice data behind a host-written VPS/SPS/PPS/slice header.  0 on success.
+   HEVCE_HOST_WRITER=1 in the environment: the host replays the decision records into the stream instead (cross-check) */
 int  hevce_job_run(hevce_job *job);
 /* the two halves of hevce_job_run, for callers that overlap them */
 int  hevce_job_launch(hevce_job *job);          /* enqueue kernel + async D2H of records */
-int  hevce_job_finish(hevce_job *job);          /* wait, then write the streams on the host */
+int  hevce_job_finish(hevce_job *job);          /* wait, then assemble the streams (header + device-emitted slice data) */
 /* results */
 const unsigned char *hevce_job_stream(hevce_job *job, int i, int *length);
 int  hevce_job_padded_size(hevce_job *job, int i, int *ysz, int *xsz);
@@ -59,7 +61,7 @@ int  hevce_job_download_rcon(hevce_job *job, int i, unsigned char *img_rcon);
 void *hevce_job_device_rcon(hevce_job *job, int i);
 void *hevce_job_device_records(hevce_job *job, int i);
 int  hevce_job_download_records(hevce_job *job, int i, unsigned char *records, int *ctu_state /* 8 ints per CTU, may be NULL */);
-/* timings of the last run, milliseconds: kernel (HIP events on the launch stream), D2H wait, host writer */
+/* timings of the last run, milliseconds: kernel (HIP events on the launch stream), D2H wait, stream assembly on the host */
 int  hevce_job_timings(hevce_job *job, float *kernel_ms, float *d2h_ms, float *writer_ms);
 
 /* diagnostics and function-level test hooks */

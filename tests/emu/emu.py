@@ -37,7 +37,11 @@ def analyse(img, q, want_dump=False):
     st = np.zeros((nctu, 8), np.int32)
     rcon = np.zeros((H, W), np.uint8)
     dump = np.zeros((nctu, 21, 72, 16), np.int32) if want_dump else None
+    payload = np.zeros(nctu * 3200 + 64, np.uint8)
+    plen = C.c_int32(-1)
     rc = lib().emu_analyse(img.ctypes.data_as(_u8p), h, w, q, rcon.ctypes.data_as(_u8p), rec.ctypes.data_as(_u8p),
-                           st.ctypes.data_as(C.POINTER(C.c_int32)), dump.ctypes.data_as(C.POINTER(C.c_int32)) if want_dump else None)
+                           st.ctypes.data_as(C.POINTER(C.c_int32)), dump.ctypes.data_as(C.POINTER(C.c_int32)) if want_dump else None,
+                           payload.ctypes.data_as(_u8p), C.byref(plen))
     assert rc == 0, "emulator deadlock"
+    analyse.payload = bytes(payload[:max(plen.value, 0)])          # the slice data the device emitted itself
     return (rec, rcon, st, dump) if want_dump else (rec, rcon, st)

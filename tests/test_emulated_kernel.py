@@ -21,3 +21,7 @@ def test_emulated_kernel_matches_golden(path):
     assert np.array_equal(rcon, c["rcon"])
     assert np.array_equal(st, c["ctu_state"])
     assert np.array_equal(rec, c["records"])
+    # device-side byte emission: the golden stream minus its VPS/SPS/PPS/slice header
+    stream = bytes(c["stream"])
+    assert len(emu.analyse.payload) > 0 and stream.endswith(emu.analyse.payload)
+    assert len(stream) - len(emu.analyse.payload) in range(70, 100)

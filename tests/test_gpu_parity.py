@@ -146,3 +146,21 @@ def test_upper_left_crop_is_prefix_consistent(hevce, orc):
         ra, sa = job.records(0)
         rb, sb = job.records(1)
     assert np.array_equal(ra[:7], rb[:7]) and np.array_equal(sa[:7], sb[:7])   # the last CTU differs only by its terminate bin
+
+
+@pytest.mark.gpu
+def test_device_emitted_stream_equals_host_writer_replay():
+    """the kernel emits the slice data itself (default); HEVCE_HOST_WRITER=1 makes the host replay the decision
+    records instead.  Both must give the same bytes, and hevce_write_stream() on the downloaded records as well."""
+    import subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import hevce_pkg, hevce_workload as wl; h = hevce_pkg.load();"
+            "imgs = [wl.gen_g2(200, 328, 16, seed=5), wl.gen_g2(97, 65, 4, seed=6), wl.gen_g2(32, 32, 48, seed=7)];"
+            "out = h.encode_batch(imgs, [2, 0, 4]);"
+            "print(' '.join(hashlib.sha256(s).hexdigest() for s, _ in out))" % ROOT)
+    env = dict(os.environ); env.pop("HEVCE_HOST_WRITER", None)
+    b = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    env["HEVCE_HOST_WRITER"] = "1"
+    c = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert b.returncode == 0 and c.returncode == 0, (b.stderr, c.stderr)
+    assert b.stdout.strip() == c.stdout.strip() and len(b.stdout.split()) == 3
