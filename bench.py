@@ -3,7 +3,8 @@
 
 A step = one pass of the hot path over one batch of synthetic input: every rank encodes ONE 3840x2160 G2-16 picture
 (BASELINE.json configs[1]; pads to 3840x2176 = 8160 CTUs) that is already resident in HBM: analysis
-kernel -> D2H of the decision records -> host stream writer -> complete .h265 bytes.  Images are independent, so with
+analysis kernel (which also emits the slice data) -> D2H of the decision records and the slice data behind a
+host-written header -> complete .h265 bytes.  Images are independent, so with
 N ranks each rank encodes its own picture (seed + rank, weak scaling, no data-path collective); the only exchange is
 the gather of the finished streams to rank 0 over RCCL, inside the timed region.
 
@@ -83,7 +84,7 @@ def main():
     gathered = {}
 
     def step():
-        job.run()                                              # kernel + D2H + host writer: .h265 complete
+        job.run()                                              # kernel + D2H + header: .h265 complete
         s = job.stream(0)
         if world > 1:                                          # gather the finished streams on rank 0 (RCCL over xGMI)
             n = torch.tensor([len(s)], dtype=torch.int64, device=dev)
@@ -146,14 +147,14 @@ def main():
             "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {"workload": f"one {args.width}x{args.height} G2-16 grayscale picture per GPU (seed 0x1234ABCD+rank), "
                                    f"qpd6={args.qpd6}, padded {W}x{H} = {nctu} CTUs, input resident in HBM; "
-                                   "kernel + D2H records + host CABAC writer" + ("; RCCL gather of streams to rank 0" if world > 1 else ""),
+                                   "kernel (analysis + slice-data emission) + D2H + header" + ("; RCCL gather of streams to rank 0" if world > 1 else ""),
                        "images_per_gpu": 1, "parallelism": f"image-per-gpu x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 6), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 9), "traffic": traffic,
                          "kernel": "hevce_analyse_kernel", "kernel_ms_avg": round(k_avg, 3),
                          "us_per_ctu": round(k_avg * 1e3 / nctu, 2),
                          "note": "serial-dependency bound by construction (SURVEY 0.2): one picture = one workgroup chain"},
-            "phases_ms": {"kernel": round(k_avg, 2), "d2h": round(float(np.mean(d2h_ms)), 2), "host_writer": round(float(np.mean(writer_ms)), 2)},
+            "phases_ms": {"kernel": round(k_avg, 2), "d2h": round(float(np.mean(d2h_ms)), 2), "host_assembly": round(float(np.mean(writer_ms)), 2)},
             "stream_bytes": len(first), "stream_sha256": hashlib.sha256(first).hexdigest(),
         }
         if world == 1 and not args.no_cpu_baseline:
