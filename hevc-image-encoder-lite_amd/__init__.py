@@ -56,6 +56,10 @@ def lib():
         L.hevce_job_destroy.argtypes = [C.c_void_p]
         L.hevce_job_upload.argtypes = [C.c_void_p, C.c_int, _u8p]
         L.hevce_job_set_device_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.hevce_job_upload_window.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+        L.hevce_job_set_device_window.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+        L.HEVCImageEncoderTiles.restype = C.c_int
+        L.HEVCImageEncoderTiles.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_u8p), _i32p, C.POINTER(_u8p)]
         L.hevce_job_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         for f in ("hevce_job_run", "hevce_job_launch", "hevce_job_finish"):
             getattr(L, f).argtypes = [C.c_void_p]
@@ -168,6 +172,19 @@ class Job:
         self._keep[i] = keepalive
         _check(lib().hevce_job_set_device_image(self._h, i, C.c_void_p(ptr)), "hevce_job_set_device_image")
 
+    def upload_window(self, i, picture, y0, x0):
+        """image i = the window of this job's size at (y0, x0) of a larger host picture (copied with its stride)."""
+        picture = np.ascontiguousarray(picture, np.uint8)
+        h, w = self.sizes[i]
+        assert 0 <= y0 and 0 <= x0 and y0 + h <= picture.shape[0] and x0 + w <= picture.shape[1]
+        origin = picture.ctypes.data + y0 * picture.shape[1] + x0
+        _check(lib().hevce_job_upload_window(self._h, i, C.c_void_p(origin), picture.shape[1]), "hevce_job_upload_window")
+
+    def set_device_window(self, i, origin_ptr, stride, keepalive=None):
+        """image i = a window of a larger picture resident in HBM, read in place (origin pointer, row stride in bytes)."""
+        self._keep[i] = keepalive
+        _check(lib().hevce_job_set_device_window(self._h, i, C.c_void_p(origin_ptr), int(stride)), "hevce_job_set_device_window")
+
     def set_stream(self, hip_stream):
         _check(lib().hevce_job_set_stream(self._h, C.c_void_p(hip_stream)), "hevce_job_set_stream")
 
@@ -232,3 +249,27 @@ def encode_batch(imgs, qpd6, device=0):
             job.upload(i, im)
         job.run()
         return [(job.stream(i), job.rcon(i)) for i in range(job.n)]
+
+
+def tile_grid(h, w, tile_h, tile_w):
+    """[(y0, x0, th, tw), ...] in the raster order HEVCImageEncoderTiles uses."""
+    return [(y, x, min(tile_h, h - y), min(tile_w, w - x)) for y in range(0, h, tile_h) for x in range(0, w, tile_w)]
+
+
+def encode_tiles(img, qpd6, tile_h, tile_w, want_rcon=True):
+    """One picture as independent tile-pictures (SURVEY 8d config 4): returns [(y0, x0, stream, rcon-or-None), ...];
+    every stream is what HEVCImageEncoder gives for that window stored as a picture of its own."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    if not (1 <= int(tile_h) <= 8192 and 1 <= int(tile_w) <= 8192):
+        raise HevceError("encode_tiles: tile sizes must be 1..8192 (the reference's picture limit, HEVCe.c:1581-1582)")
+    grid = tile_grid(h, w, tile_h, tile_w)
+    outs = [np.empty(int(lib().hevce_stream_bound(th, tw)), np.uint8) for (_, _, th, tw) in grid]
+    rcons = [np.empty((pad32(th), pad32(tw)), np.uint8) if want_rcon else None for (_, _, th, tw) in grid]
+    lens = np.zeros(len(grid), np.int32)
+    pb = (_u8p * len(grid))(*[_p(o) for o in outs])
+    pr = (_u8p * len(grid))(*[_p(r) if r is not None else None for r in rcons])
+    n = lib().HEVCImageEncoderTiles(_p(img), h, w, int(tile_h), int(tile_w), int(qpd6), pb, _p(lens, _i32p), pr)
+    _check(n, "HEVCImageEncoderTiles")
+    assert n == len(grid)
+    return [(y, x, outs[t][:lens[t]].tobytes(), rcons[t]) for t, (y, x, _, _) in enumerate(grid)]

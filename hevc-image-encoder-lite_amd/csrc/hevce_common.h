@@ -53,12 +53,13 @@ typedef struct HevceCoderRegs {
 
 /* one image of a batch, as the kernel sees it (all pointers are device pointers) */
 typedef struct HevceImageDesc {
-    const uint8_t *img;       /* src_h x src_w luma, stride src_w */
+    const uint8_t *img;       /* src_h x src_w luma, row stride src_stride (>= src_w: the picture may be a window of a larger one) */
     uint8_t       *rcon;      /* H x W reconstruction, stride W */
     uint8_t       *records;   /* (H/32)*(W/32) HevceRecord, raster CTU order */
     int32_t       *ctu_state; /* optional: 8 ints per CTU (coder registers after the CTU) */
     uint8_t       *scratch;   /* HEVCE_SCRATCH_BYTES of per-image trial scratch */
     int32_t src_h, src_w, H, W, qpd6, status;
+    int64_t src_stride;
     int32_t       *dump;      /* diagnostics: per CU evaluation, 72 x (sse, cost) ints (NULL = off) */
     int32_t       *trace;     /* diagnostics: host-pinned, 16 ints per wavefront (only written by HEVCE_TRACE builds) */
     /* device-side byte emission; all three NULL = off, the host writer replays the records instead */

@@ -1991,7 +1991,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
             /* ---- load the CTU: source samples (edge-replicated), neighbours, maps  [ref :1611-1622] ---- */
             for (int p = tid; p < 1024; p += HV_NTHREADS) {
                 const int yy = hv_min(y0 + (p >> 5), im.src_h - 1), xx = hv_min(x0 + (p & 31), im.src_w - 1);
-                S.org[p >> 5][p & 31] = im.img[(size_t)yy * im.src_w + xx];
+                S.org[p >> 5][p & 31] = im.img[(size_t)yy * (size_t)im.src_stride + xx];
             }
             if (tid < 32) S.rec[1 + tid][HV_RX - 1] = L ? S.rec[1 + tid][HV_RX + 31] : 128;   /* left column = previous CTU's last column */
             BLOCK_SYNC();

@@ -56,6 +56,7 @@ struct Image {
     size_t off_payload, off_leadlog, off_plen;                   /* device-side byte emission: slice data, byte log, length */
     size_t hoff_rec, hoff_state, hoff_plen;                      /* into the pinned host slab */
     const void *ext_img = nullptr;
+    long ext_stride = 0;                                         /* row stride of ext_img (0: w0) */
     std::vector<uint8_t> stream;
     int length = 0;
 };
@@ -155,15 +156,33 @@ int hevce_job_upload(hevce_job *j, int i, const unsigned char *img) {
     if (!j || i < 0 || i >= j->n) return fail("hevce_job_upload: bad arguments");
     HIPCHK(hipSetDevice(j->device));
     Image &m = j->im[i];
-    m.ext_img = nullptr; j->desc_dirty = true;
+    m.ext_img = nullptr; m.ext_stride = 0; j->desc_dirty = true;
     HIPCHK(hipMemcpyAsync(j->d_slab + m.off_img, img, size_t(m.h0) * m.w0, hipMemcpyHostToDevice, j->stream));
+    HIPCHK(hipStreamSynchronize(j->stream));
+    return 0;
+}
+
+/* picture i = the h0 x w0 window at `origin` of a larger host picture with row stride `stride` (tile-pictures) */
+int hevce_job_upload_window(hevce_job *j, int i, const unsigned char *origin, long stride) {
+    if (!j || i < 0 || i >= j->n || !origin || stride < j->im[i].w0) return fail("hevce_job_upload_window: bad arguments");
+    HIPCHK(hipSetDevice(j->device));
+    Image &m = j->im[i];
+    m.ext_img = nullptr; m.ext_stride = 0; j->desc_dirty = true;
+    HIPCHK(hipMemcpy2DAsync(j->d_slab + m.off_img, size_t(m.w0), origin, size_t(stride), size_t(m.w0), size_t(m.h0), hipMemcpyHostToDevice, j->stream));
     HIPCHK(hipStreamSynchronize(j->stream));
     return 0;
 }
 
 int hevce_job_set_device_image(hevce_job *j, int i, const void *d_img) {
     if (!j || i < 0 || i >= j->n) return fail("hevce_job_set_device_image: bad arguments");
-    j->im[i].ext_img = d_img; j->desc_dirty = true;
+    j->im[i].ext_img = d_img; j->im[i].ext_stride = 0; j->desc_dirty = true;
+    return 0;
+}
+
+/* picture i = the h0 x w0 window at `d_origin` of a larger picture resident in HBM, read in place */
+int hevce_job_set_device_window(hevce_job *j, int i, const void *d_origin, long stride) {
+    if (!j || i < 0 || i >= j->n || !d_origin || stride < j->im[i].w0) return fail("hevce_job_set_device_window: bad arguments");
+    j->im[i].ext_img = d_origin; j->im[i].ext_stride = stride; j->desc_dirty = true;
     return 0;
 }
 
@@ -188,7 +207,7 @@ int hevce_job_launch(hevce_job *j) {
             d.records = j->d_slab + m.off_rec;
             d.ctu_state = (int32_t *)(j->d_slab + m.off_state);
             d.scratch = j->d_slab + m.off_scratch;
-            d.src_h = m.h0; d.src_w = m.w0; d.H = m.H; d.W = m.W; d.qpd6 = m.q; d.status = 0;
+            d.src_h = m.h0; d.src_w = m.w0; d.src_stride = (m.ext_img && m.ext_stride) ? m.ext_stride : m.w0; d.H = m.H; d.W = m.W; d.qpd6 = m.q; d.status = 0;
             d.trace = j->h_trace ? j->h_trace + 1024 * i : nullptr;
             d.payload = j->device_emit ? j->d_slab + m.off_payload : nullptr;
             d.leadlog = j->device_emit ? (uint16_t *)(j->d_slab + m.off_leadlog) : nullptr;
@@ -382,6 +401,39 @@ int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned 
     }
     hevce_job_destroy(j);
     return rc;
+}
+
+/* one picture as independent tile-pictures, each with its own header and stream, all in one launch.
+   Tiles in raster order; tile (r, c) is the window rows [r*tile_ysz, min(ysz, (r+1)*tile_ysz)), columns likewise. */
+int HEVCImageEncoderTiles(const unsigned char *img, int ysz, int xsz, int tile_ysz, int tile_xsz, int qpd6,
+                          unsigned char *const *pbuffers, int *lengths, unsigned char *const *img_rcons) {
+    if (!img || ysz <= 0 || xsz <= 0 || tile_ysz <= 0 || tile_xsz <= 0 || tile_ysz > HEVCE_MAXDIM || tile_xsz > HEVCE_MAXDIM || !pbuffers)
+        return fail("HEVCImageEncoderTiles: bad arguments (tile sizes must be 1..%d)", HEVCE_MAXDIM);
+    const int rows = (ysz + tile_ysz - 1) / tile_ysz, cols = (xsz + tile_xsz - 1) / tile_xsz;
+    if ((long)rows * cols > (1 << 20)) return fail("HEVCImageEncoderTiles: more than 2^20 tiles");
+    const int n = rows * cols;
+    std::vector<int> hs(n), ws(n), qs(n, qpd6);
+    for (int t = 0; t < n; t++) {
+        const int r = t / cols, c = t % cols;
+        hs[t] = ysz - r * tile_ysz < tile_ysz ? ysz - r * tile_ysz : tile_ysz;
+        ws[t] = xsz - c * tile_xsz < tile_xsz ? xsz - c * tile_xsz : tile_xsz;
+    }
+    int device = 0;
+    if (const char *e = getenv("HEVCE_DEVICE")) device = atoi(e);
+    hevce_job *j = hevce_job_create(device, n, hs.data(), ws.data(), qs.data());
+    if (!j) return -1;
+    int rc = 0;
+    for (int t = 0; t < n && rc == 0; t++)
+        rc = hevce_job_upload_window(j, t, img + (size_t)(t / cols) * tile_ysz * (size_t)xsz + (size_t)(t % cols) * tile_xsz, xsz);
+    if (rc == 0) rc = hevce_job_run(j);
+    for (int t = 0; t < n && rc == 0; t++) {
+        const Image &m = j->im[t];
+        memcpy(pbuffers[t], m.stream.data(), (size_t)m.length);
+        if (lengths) lengths[t] = m.length;
+        if (img_rcons && img_rcons[t]) rc = hevce_job_download_rcon(j, t, img_rcons[t]);
+    }
+    hevce_job_destroy(j);
+    return rc == 0 ? n : -1;
 }
 
 __attribute__((visibility("default"))) int HEVCImageEncoder(unsigned char *pbuffer, const unsigned char *img, unsigned char *img_rcon,

@@ -32,6 +32,17 @@ int HEVCImageEncoder(unsigned char *pbuffer, const unsigned char *img, unsigned 
 int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs,
                           unsigned char *const *img_rcons, int *yszs, int *xszs, const int *qpd6s, int *lengths);
 
+/* ---- additive: ONE picture as independent tile-pictures ---------------------
+ * The reference crops pictures to 8192 x 8192 (HEVCe.c:1581-1582) and one picture is one serial chain; a larger
+ * picture, or any picture that should occupy more than one compute unit, is cut into tiles that are encoded as
+ * pictures of their own (own VPS/SPS/PPS/slice header, own coder) in one launch.  Tile t = r*cols + c (raster order,
+ * rows = ceil(ysz/tile_ysz), cols = ceil(xsz/tile_xsz)) covers rows [r*tile_ysz, min(ysz, (r+1)*tile_ysz)) and the
+ * columns likewise; pbuffers[t] / lengths[t] / img_rcons[t] are what HEVCImageEncoder() would produce for that
+ * window stored as a picture (edge tiles are padded to multiples of 32 on their own).  img_rcons or single entries
+ * of it may be NULL.  tile sizes: 1..8192.  Returns the number of tiles, or a negative value. */
+int HEVCImageEncoderTiles(const unsigned char *img, int ysz, int xsz, int tile_ysz, int tile_xsz, int qpd6,
+                          unsigned char *const *pbuffers, int *lengths, unsigned char *const *img_rcons);
+
 /* upper bound of the stream size for a picture of the given (unpadded) size */
 long hevce_stream_bound(int ysz, int xsz);
 
@@ -43,8 +54,12 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
 void       hevce_job_destroy(hevce_job *job);
 /* copy image i from host memory (stride = xszs[i]) into the job's HBM buffer */
 int  hevce_job_upload(hevce_job *job, int i, const unsigned char *img);
+/* the same from a window of a larger host picture: yszs[i] rows of xszs[i] samples at origin, row stride `stride` */
+int  hevce_job_upload_window(hevce_job *job, int i, const unsigned char *origin, long stride);
 /* use an image that already lives in HBM (e.g. a torch tensor's data_ptr); the job does not own it */
 int  hevce_job_set_device_image(hevce_job *job, int i, const void *d_img);
+/* image i is a window of a larger picture in HBM, read in place (no copy): origin pointer + row stride in bytes */
+int  hevce_job_set_device_window(hevce_job *job, int i, const void *d_origin, long stride);
 /* run on this hipStream_t (NULL = the job's own stream) */
 int  hevce_job_set_stream(hevce_job *job, void *hip_stream);
 /* analysis kernel over all images (it also emits each image's slice data) + D2H of the decision records and of the

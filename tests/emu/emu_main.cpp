@@ -72,7 +72,7 @@ int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, 
     im.dump = dump;
     std::vector<uint16_t> leadlog(2 * HEVCE_LEADLOG_WORDS, 0xABCD);
     if (payload) { im.payload = payload; im.payload_len = payload_len; im.leadlog = leadlog.data(); }     /* device-side byte emission on */
-    im.src_h = src_h; im.src_w = src_w; im.qpd6 = q;
+    im.src_h = src_h; im.src_w = src_w; im.src_stride = src_w; im.qpd6 = q;
     im.H = ((src_h < HEVCE_MAXDIM ? src_h : HEVCE_MAXDIM) + 31) / 32 * 32;
     im.W = ((src_w < HEVCE_MAXDIM ? src_w : HEVCE_MAXDIM) + 31) / 32 * 32;
     std::vector<uint8_t> scratch(HEVCE_SCRATCH_BYTES, 0xCD);

@@ -57,3 +57,18 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".h", ".hip", ".cpp", ".c", ".py", "Makefile", ".map")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle/" not in txt and "hevce_oracle" not in txt and "orc_" not in txt, os.path.join(dp, f)
+
+
+def test_tile_grid_and_tile_entry_point_without_gpu(hevce):
+    """SURVEY 8(d) config 4 host logic: raster order, ragged edge tiles, argument checks; without a GPU the tile entry
+    point fails loudly like every other entry point (no CPU fallback)."""
+    g = hevce.tile_grid(200, 330, 96, 160)
+    assert g == [(y, x, min(96, 200 - y), min(160, 330 - x)) for y in (0, 96, 192) for x in (0, 160, 320)]
+    assert hevce.tile_grid(16384, 16384, 8192, 4096)[-1] == (8192, 12288, 8192, 4096) and len(hevce.tile_grid(16384, 16384, 1024, 1024)) == 256
+    img = np.zeros((64, 64), np.uint8)
+    for th, tw in ((0, 32), (32, 0), (8193, 32)):
+        with pytest.raises(hevce.HevceError):
+            hevce.encode_tiles(img, 2, th, tw)
+    if hevce.device_count() <= 0:
+        with pytest.raises(hevce.HevceError):
+            hevce.encode_tiles(img, 2, 32, 32)
