@@ -204,7 +204,7 @@ struct alignas(16) HvLds {
     int nxn_busy;                                           /* 1 while wavefront 0 walks the NxN chain of the current 8x8 CU */
     /* device-side byte emission: the CTU's finished bytes are collected in coding order (a stack: a CU that ends up unsplit
        rewinds to its mark and pushes its winner's); the previous CTU's are turned into stream bytes by wavefront 4 meanwhile */
-    int em_pos, em_mark[3], em_cnt[2];
+    int em_pos, em_mark[3], em_cnt[2], em_rd, em_slice;
     int em_held, em_pending, em_zeros, em_n;                /* the emitting coder's byte state  [ref :797-806, 821-832, 859-879] */
     unsigned long long prof[3][8];
     unsigned long long prof2[32];                           /* HEVCE_PROF: inside the NxN job (tu jobs, tokenise, engine, select) */
@@ -1494,6 +1494,7 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
         L.tregs[70] = S.ent[0];
     }
     for (int r = lane; r < HEVCE_NCTXP; r += 64) L.tctx[r][70] = S.ent_ctx[0][r];
+    HV_PROF2(S, 4);
 }
 /* distortion of the CU as currently reconstructed (the "split into four CUs" alternative)  [ref :1409] */
 static HD void hv_job_sse(HvLds &S, int lane, const HvCu &cu) {
@@ -1683,9 +1684,14 @@ static HD void hv_run_engines(HvLds &S, const HevceImageDesc &im, int mask, int 
    wavefronts on one SIMD would take turns).  finish = 0: the 8x8 candidates run to their end, the candidates of the
    enclosing CUs ride along for as long as that takes (S.l0_active counts the 8x8 engines still running);
    finish = 1 (a 16x16 / 32x32 CU is decided): what the ride-along left runs to its end. */
-static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int finish) {
+static HD void hv_emit_ctu(HvLds &S, const HevceImageDesc &im, int which, int limit);
+static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int finish, int ctu = 0) {
     const int wave = hv_tid() >> 6;
     HV_PROF_T0();
+    /* device-side byte emission: wavefront 4, idle otherwise, turns a slice of the PREVIOUS CTU's finished bytes into stream
+       bytes in each of the sixteen 8x8 engine phases -- one lane, a serial state machine; in one go it would outlast a whole
+       jobs phase, and it shares SIMD0's issue slots with wavefront 0, whose engines here have time to spare */
+    if (!finish && im.payload && ctu > 0 && hv_tid() == 4 * 64) hv_emit_ctu(S, im, (ctu - 1) & 1, S.em_slice);
     hv_run_engines(S, im, mask, finish ? nullptr : &S.l0_active, 4, wave < 4 ? wave : -1);
     BLOCK_SYNC();
     HV_PROF(S, 0, 6);
@@ -1729,21 +1735,30 @@ static HD void hv_em_put(HvEmit &e, int byte) {
 }
 static HD HvEmit hv_em_load(const HvLds &S, const HevceImageDesc &im) { HvEmit e = { S.em_held, S.em_pending, S.em_zeros, S.em_n, (HV_GLOBAL u8 *)im.payload }; return e; }
 static HD void hv_em_store(HvLds &S, const HvEmit &e) { S.em_held = e.held; S.em_pending = e.pending; S.em_zeros = e.zeros; S.em_n = e.n; }
-static HD void hv_emit_ctu(HvLds &S, const HevceImageDesc &im, int which) {
-    const HV_GLOBAL u16 *log = (const HV_GLOBAL u16 *)im.leadlog + which * HEVCE_LEADLOG_WORDS;
-    const int n = S.em_cnt[which];
+/* records [S.em_rd, S.em_rd + limit) of log `which`, fetched eight at a time one chunk ahead.  One lane (wavefront 4, lane 0). */
+static HD void hv_emit_ctu(HvLds &S, const HevceImageDesc &im, int which, int limit) {
+    const HV_GLOBAL HvChunk *log8 = (const HV_GLOBAL HvChunk *)((const HV_GLOBAL u16 *)im.leadlog + which * HEVCE_LEADLOG_WORDS);
+    const int n = S.em_cnt[which], pos = S.em_rd, end = hv_min(n, pos + hv_min(limit, HEVCE_LEADLOG_WORDS));
+    if (pos >= end) return;
     HvEmit e = hv_em_load(S, im);
-    for (int i = 0; i < n; i++) {
-        const int lead = log[i & (HEVCE_LEADLOG_WORDS - 1)];
-        if (lead == 0xff) { e.pending++; continue; }
-        if (e.pending > 0) {
-            const int c = lead >> 8, fill = (0xff + c) & 0xff;
-            hv_em_put(e, e.held + c);
-            e.held = lead & 0xff;
-            for (; e.pending > 1; e.pending--) hv_em_put(e, fill);
-        } else { e.pending = 1; e.held = lead; }                 /* first byte ever: stored unmasked, as the reference does */
+    HvChunk nxt = log8[(pos >> 3) & (HEVCE_LEADLOG_WORDS / 8 - 1)];
+    for (int base = pos & ~7; base < end; base += 8) {
+        const HvChunk cur = nxt;
+        nxt = log8[((base >> 3) + 1) & (HEVCE_LEADLOG_WORDS / 8 - 1)];
+        for (int j = 0; j < 8; j++) {
+            if (base + j < pos || base + j >= end) continue;
+            const int lead = (int)((cur[j >> 1] >> ((j & 1) << 4)) & 0xffffu);
+            if (lead == 0xff) { e.pending++; continue; }
+            if (e.pending > 0) {
+                const int c = lead >> 8, fill = (0xff + c) & 0xff;
+                hv_em_put(e, e.held + c);
+                e.held = lead & 0xff;
+                for (; e.pending > 1; e.pending--) hv_em_put(e, fill);
+            } else { e.pending = 1; e.held = lead; }             /* first byte ever: stored unmasked, as the reference does */
+        }
     }
     hv_em_store(S, e);
+    S.em_rd = end;
 }
 static HD void hv_emit_finish(HvLds &S, const HevceImageDesc &im) {
     HvEmit e = hv_em_load(S, im);
@@ -1782,11 +1797,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         hv_job_nxn(wave, lane, q, c8, (HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3) + (size_t)70 * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0);
         return;
     }
-    if (wv == 4) {                                               /* shares its SIMD with wavefront 0: idle, except that once per CTU it
-                                                                    turns the previous CTU's finished bytes into stream bytes */
-        if (im.payload && k16 == 0 && m == 0 && ctu > 0 && lane == 0) hv_emit_ctu(S, im, (ctu - 1) & 1);
-        return;
-    }
+    if (wv == 4) return;                                         /* shares its SIMD with wavefront 0: idle */
     const int w1 = wv < 4 ? wv - 1 : wv - 2;                     /* work slot 0..5 */
     HvGLev l0 = (HvGLev)s0, l1 = (HvGLev)s1, l2 = (HvGLev)s2;
     HvGRec r0 = (HvGRec)(s0 + HV_TL * 1024 * 2), r1 = (HvGRec)(s1 + HV_TL * 1024 * 2), r2 = (HvGRec)(s2 + HV_TL * 1024 * 2);
@@ -1945,7 +1956,7 @@ static HD void hv_init_tables(HvLds &S, int q, int tid) {
         const u8 v = (u8)(st >= 64 ? (((st - 64) << 1) | 1) : ((63 - st) << 1));
         S.ctx_fresh[i] = v; S.com_ctx[i] = v;
     }
-    if (tid == 301) { S.em_pos = 0; S.em_cnt[0] = S.em_cnt[1] = 0; S.em_held = 0xff; S.em_pending = 0; S.em_zeros = 0; S.em_n = 0; }
+    if (tid == 301) { S.em_pos = 0; S.em_rd = 0; S.em_slice = 0; S.em_cnt[0] = S.em_cnt[1] = 0; S.em_held = 0xff; S.em_pending = 0; S.em_zeros = 0; S.em_n = 0; }
     if (tid == 300) { S.com.range = 510; S.com.low = 0; S.com.nbits = 23; S.com.nbytes = 0; S.com.bufbyte = 0xff; S.com.zeros = 0; S.com.nout = 0; S.com.pad = 0; }
 }
 
@@ -2047,11 +2058,17 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     BLOCK_SYNC();
                     HV_PROF_T0();
                     hv_jobs_phase(S, im, cu, c16, c32, k, m, ctu);
+#ifdef HEVCE_PROF_WAIT
+                    const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
                     BLOCK_SYNC();                                /* the NxN job borrows the 8x8 level's context columns */
+#ifdef HEVCE_PROF_WAIT
+                    if (tid == 0) S.prof2[16 + k * 4 + m] += __builtin_amdgcn_s_memtime() - w0_;
+#endif
                     HV_PROF(S, 0, 0);
                     if (m == 0) hv_level_contexts(S, im, c16);
                     if (k == 1 && m == 2) hv_level_contexts(S, im, c32);     /* its jobs ran in five phases up to this one */
-                    hv_engine_phase(S, im, 1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0), 0);
+                    hv_engine_phase(S, im, 1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0), 0, ctu);
                 }
                 hv_decide_cu(S, im, cu, ctu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr);
             }
@@ -2062,7 +2079,9 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                 hv_cod_load(c, S.com);
                 hv_terminate(c, (y0 + 32 >= H) && (x0 + 32 >= W), im.leadlog ? (HV_GLOBAL u16 *)im.leadlog + (ctu & 1) * HEVCE_LEADLOG_WORDS : nullptr, &S.em_pos);
                 hv_cod_store(S.com, c);
-                S.em_cnt[ctu & 1] = S.em_pos; S.em_pos = 0;      /* this CTU's bytes are complete: wavefront 4 emits them during the next CTU */
+                if (im.payload && ctu > 0) hv_emit_ctu(S, im, (ctu - 1) & 1, HEVCE_LEADLOG_WORDS);   /* what the slices left of the previous CTU's (normally nothing) */
+                S.em_cnt[ctu & 1] = S.em_pos; S.em_pos = 0;      /* this CTU's bytes are complete: wavefront 4 emits them during the next CTU, */
+                S.em_rd = 0; S.em_slice = (S.em_cnt[ctu & 1] + 13) / 14;   /* in fourteen of its sixteen engine phases */
                 if (im.ctu_state) {
                     int32_t *st = im.ctu_state + (size_t)ctu * 8;
                     st[0] = c.range; st[1] = (int32_t)c.low; st[2] = c.nbits; st[3] = c.nbytes; st[4] = c.bufbyte; st[5] = c.zeros;
@@ -2076,7 +2095,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
             BLOCK_SYNC();
         }
     }
-    if (im.payload && tid == 0) { hv_emit_ctu(S, im, (ctu - 1) & 1); hv_emit_finish(S, im); }   /* the last CTU's bytes and the coder's tail */
+    if (im.payload && tid == 0) { hv_emit_ctu(S, im, (ctu - 1) & 1, HEVCE_LEADLOG_WORDS); hv_emit_finish(S, im); }   /* the last CTU's bytes and the coder's tail */
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     if (im.trace && tid < 24) { ((unsigned long long *)im.trace)[tid] = (&S.prof[0][0])[tid]; }
     if (im.trace && tid < 32) { ((unsigned long long *)im.trace)[24 + tid] = S.prof2[tid]; }
