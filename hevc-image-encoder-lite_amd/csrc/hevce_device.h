@@ -1712,15 +1712,25 @@ static HD void hv_bin_own(HvLds &S, const HevceImageDesc &im, const HvCu cu, int
     const HvCnt cn = { (HV_LDSP u8 *)&S.ws[hv_tid() >> 6] + 4096, tb };
     HV_FENCE_RELEASE();                                          /* the jobs' levels in HBM, their results in LDS */
     WAVE_SYNC();
+#ifdef HEVCE_PROF_BIN
+#define HV_BINT(i) do { if (hv_tid() == 64) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[16 + 4 * cu.lvl + (i)] += n_ - bt_; bt_ = n_; } } while (0)
+    unsigned long long bt_ = __builtin_amdgcn_s_memtime();
+#else
+#define HV_BINT(i) do { } while (0)
+#endif
     for (int c0 = 0; c0 < tc; c0 += per)
         hv_bin_group(S, L, cu, gtok, (HvGLev)scr, cn, (tb + c0 + lane / ncg) * ncg + lane % ncg, c0 + lane / ncg < tc);
+    HV_BINT(0);
     for (int j = lane; j < tc * 4; j += 64) {
         const int t = tb + (j >> 2), tu = j & 3;
         if (t >= 35 || tu == 0) hv_bin_tu_header(S, L, cu, gtok, cn, t, tu);
     }
+    HV_BINT(1);
     for (int j = lane; j < tc; j += 64) hv_bin_cu_header(S, L, cu, gtok, cn, tb + j);
     WAVE_SYNC();
+    HV_BINT(2);
     for (int j = lane; j < tc; j += 64) hv_build_slist(S, L, cn, cu.n, cu.lvl, tb + j);
+    HV_BINT(3);
 }
 
 /* Device-side byte emission  [ref CABACput :821-832, CABACupdate :859-879, CABACfinish :840-856].
@@ -2057,7 +2067,13 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     hv_level_begin(S, cu);
                     BLOCK_SYNC();
                     HV_PROF_T0();
+#ifdef HEVCE_PROF_JDUR
+                    const unsigned long long j0_ = __builtin_amdgcn_s_memtime();
+#endif
                     hv_jobs_phase(S, im, cu, c16, c32, k, m, ctu);
+#ifdef HEVCE_PROF_JDUR
+                    if (tid == HEVCE_PROF_JDUR * 64) S.prof2[16 + k * 4 + m] += __builtin_amdgcn_s_memtime() - j0_;   /* that wavefront's jobs phase, riders included */
+#endif
 #ifdef HEVCE_PROF_WAIT
                     const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
