@@ -1665,10 +1665,19 @@ static HD void hv_run_engines(HvLds &S, const HevceImageDesc &im, int mask, int 
             int dead = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0) > hv_peek(&L.best_cost);
             hv_cod_span(c);
             const int nlog = L.tnlog[t];                          /* the records stay: they are the candidate's bytes, should it win */
+#ifdef HEVCE_PROF_ENG
+            const unsigned long long e0_ = __builtin_amdgcn_s_memtime();
+#endif
             dead = hv_engine_slots(S, c, &L.tctx[0][t], slots, hv_slist(S, lvl, t), nlist, k, ci, dead, shared,
                                    shared && lvl == 0, q, L.tsse[t], bits0, &L.best_cost, sink + nlog);
+#ifdef HEVCE_PROF_ENG
+            const unsigned long long e1_ = __builtin_amdgcn_s_memtime();
+#endif
             L.tnlog[t] = nlog + c.nev;
             hv_cod_replay(c, (const HV_GLOBAL HvChunk *)sink, nlog);
+#ifdef HEVCE_PROF_ENG
+            if (nw == 4 && shared && t == 70 && lvl == 0) { S.prof2[16] += e1_ - e0_; S.prof2[17] += __builtin_amdgcn_s_memtime() - e1_; S.prof2[18] += nlist ? (S.slist0[70][0] >> 8) : 0; }
+#endif
             hv_cod_store(L.tregs[t], c);
             if (dead) { L.tdead[t] = 1; L.tcost[t] = HV_I32MAX; L.tpos[t] = -1; }
             else if (k >= nlist) {
@@ -1688,12 +1697,21 @@ static HD void hv_emit_ctu(HvLds &S, const HevceImageDesc &im, int which, int li
 static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int finish, int ctu = 0) {
     const int wave = hv_tid() >> 6;
     HV_PROF_T0();
+#ifdef HEVCE_PROF_ENG
+    const unsigned long long p0_ = __builtin_amdgcn_s_memtime();
+#endif
     /* device-side byte emission: wavefront 4, idle otherwise, turns a slice of the PREVIOUS CTU's finished bytes into stream
        bytes in each of the sixteen 8x8 engine phases -- one lane, a serial state machine; in one go it would outlast a whole
        jobs phase, and it shares SIMD0's issue slots with wavefront 0, whose engines here have time to spare */
     if (!finish && im.payload && ctu > 0 && hv_tid() == 4 * 64) hv_emit_ctu(S, im, (ctu - 1) & 1, S.em_slice);
     hv_run_engines(S, im, mask, finish ? nullptr : &S.l0_active, 4, wave < 4 ? wave : -1);
+#ifdef HEVCE_PROF_ENG
+    const unsigned long long p1_ = __builtin_amdgcn_s_memtime();
+#endif
     BLOCK_SYNC();
+#ifdef HEVCE_PROF_ENG
+    if (!finish && hv_tid() == 128) { S.prof2[19] += p1_ - p0_; S.prof2[20] += __builtin_amdgcn_s_memtime() - p1_; S.prof2[21] += 1; }
+#endif
     HV_PROF(S, 0, 6);
 }
 
