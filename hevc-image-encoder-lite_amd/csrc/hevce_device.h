@@ -797,16 +797,14 @@ static HD void hv_engine(const HvLds &S, HvCod &c, u8 *cx, ChunkPtr sp, int n, S
    (slot index | chunks << 8); (k, ci) = list entry and chunk inside that slot where work continues -- together with the
    coder registers that is all the state, so a candidate can be advanced a few chunks at a time.  Slots are whole chunks
    (padded with no-op tokens), so no token needs a range check.  `dead` on entry / return: abandoned (see hv_engine).
-   stop == nullptr: run the candidate to its end.
-   stop != nullptr: every lane stays in the loop until *stop, which other lanes / wavefronts bring down, reaches zero; a
-   candidate advances for as long as that takes.  count != nullptr: *count is decremented once, when this candidate is done.
-   The engine phase: 8x8 candidates (stop = count = &l0_active) run to their end and the candidates of the enclosing
-   CUs (count == nullptr) ride along for as long as that takes: l0_active counts the 8x8 engines still running in the whole
+   shared == nullptr: run the candidate to its end.
+   shared != nullptr: a phase in which 8x8 candidates (notify = shared) run to their end and the candidates of the enclosing
+   CUs (notify == nullptr) ride along for as long as that takes: *shared counts the 8x8 engines still running in the whole
    workgroup, and EVERY lane stays in the loop until it reaches zero; a lane that is done signals once and then idles.
    The signal is ordinary loop-body code followed by further iterations, so it is issued when the lane finishes and not
    when the slowest lane of its wavefront does -- the parents' lanes in that very wavefront are waiting for it. */
 static HD int hv_engine_slots(const HvLds &S, HvCod &c, u8 *cx, const HV_GLOBAL u16 *slots, const HV_LDSP u16 *ls, int nlist, int &k, int &ci,
-                              int dead, int *stop, int *count, int q, int sse, int bits0, int *best, HV_GLOBAL u16 *sink) {
+                              int dead, int *shared, int notify, int q, int sse, int bits0, int *best, HV_GLOBAL u16 *sink) {
     int e = ls[hv_min(k, nlist - 1)];
     int nch = e >> 8;
     const HV_GLOBAL HvChunk *ptr = (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HV_SLOT + HV_SLOT_TOK0) + ci;
@@ -819,9 +817,9 @@ static HD int hv_engine_slots(const HvLds &S, HvCod &c, u8 *cx, const HV_GLOBAL 
         if (done && !pub) {                                       /* once, at the moment the lane finishes */
             pub = 1;
             if (!dead && best && !c.zf) hv_atomic_min(best, hv_rdcost(q, sse, hv_cod_bits(c) - bits0));   /* exact (see hv_cod_span): tightens everyone's pruning bound */
-            if (count) hv_atomic_dec(count);
+            if (notify) hv_atomic_dec(shared);
         }
-        if (stop ? (hv_poll(stop) <= 0) : done) break;
+        if (shared ? (hv_poll(shared) <= 0) : done) break;
         if (!done) {
             const HvChunk cur = nxt;
             ci++;                                                 /* where the chunk after this one lives; request it now */
@@ -1649,15 +1647,11 @@ static HD void hv_level_contexts(HvLds &S, const HevceImageDesc &im, const HvCu 
    shared == nullptr: everything selected runs to its end.  Otherwise *shared is a count that other lanes / wavefronts bring
    to zero, and the candidates ride along until it gets there (8x8 candidates, if selected, run to their end and are the
    ones that count it down). */
-static HD void hv_run_engines(HvLds &S, const HevceImageDesc &im, int mask, int *shared, int nw, int ew, int own_tb = 0, int own_tc = 0) {
+static HD void hv_run_engines(HvLds &S, const HevceImageDesc &im, int mask, int *shared, int nw, int ew) {
     const int lane = hv_tid() & 63, q = im.qpd6;
     const int per = HV_TL / nw;
-    int lvl = lane / per, t = (lane % per) * nw + ew;
-    /* own_tc > 0 (a job wavefront in its idle time): the lanes behind the riders start the 8x8 candidates [own_tb, own_tb +
-       own_tc) this wavefront has just binarised itself -- nobody else touches them before the next workgroup barrier */
-    const int own = lane >= 3 * per && lane < 3 * per + own_tc;
-    if (own) { lvl = 0; t = own_tb + lane - 3 * per; }
-    if (ew >= 0 && lvl < 3 && (own || ((mask >> lvl) & 1))) {
+    const int lvl = lane / per, t = (lane % per) * nw + ew;
+    if (ew >= 0 && lvl < 3 && ((mask >> lvl) & 1)) {
         HvLds::Level &L = S.lv[lvl];
         const int ntrials = (lvl == 0) ? 71 : 70;
         if (t < ntrials && L.tpos[t] >= 0) {
@@ -1675,7 +1669,7 @@ static HD void hv_run_engines(HvLds &S, const HevceImageDesc &im, int mask, int 
             const unsigned long long e0_ = __builtin_amdgcn_s_memtime();
 #endif
             dead = hv_engine_slots(S, c, &L.tctx[0][t], slots, hv_slist(S, lvl, t), nlist, k, ci, dead, shared,
-                                   (shared && lvl == 0) ? &S.l0_active : nullptr, q, L.tsse[t], bits0, &L.best_cost, sink + nlog);
+                                   shared && lvl == 0, q, L.tsse[t], bits0, &L.best_cost, sink + nlog);
 #ifdef HEVCE_PROF_ENG
             const unsigned long long e1_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -1841,14 +1835,13 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         HV_JOBT(9, hv_job_single<8>(wave, lane, q, c8, 2 * (w1 - 3), l0, r0));
         if (w1 < 5) HV_JOBT(9, hv_job_single<8>(wave, lane, q, c8, 2 * (w1 - 3) + 1, l0, r0));
     }
-    const int tb8 = w1 < 3 ? 35 + 16 * w1 : 16 * (w1 - 3), tc8 = hv_min(16, (w1 < 3 ? 70 : 35) - tb8);
-    hv_bin_own(S, im, c8, tb8, tc8);
-    if (lane < tc8) {   /* the engines of this wavefront's 8x8 candidates start from the CU's entry snapshot  [ref :1423-1424] */
+    hv_bin_own(S, im, c8, w1 < 3 ? 35 + 16 * w1 : 16 * (w1 - 3), hv_min(16, (w1 < 3 ? 70 : 35) - (w1 < 3 ? 35 + 16 * w1 : 16 * (w1 - 3))));
+    {   /* the 8x8 candidates' engines start from the CU's entry snapshot  [ref :1423-1424] */
         HvLds::Level &L0 = S.lv[0];
-        for (int r = 0; r < HEVCE_NCTXP; r++) L0.tctx[r][tb8 + lane] = S.ent_ctx[0][r];
-        L0.tregs[tb8 + lane] = S.ent[0];
+        const int t6 = w1 * 64 + lane;
+        for (int k = t6; k < HEVCE_NCTXP * HV_TL; k += 384) L0.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[0][k / HV_TL];
+        if (t6 < 71) L0.tregs[t6] = S.ent[0];
     }
-    WAVE_SYNC();
     if (m == 0) {
         /* 16x16: 5 chains (8 modes each) on slots 0..4, 9 single TUs (4 modes each): one each on slots 0..4, four on slot 5 */
         if (w1 < 5) { HV_JOBT(10, hv_job_chain<8>(wave, lane, q, c16, w1, l1, r1)); HV_JOBT(11, hv_job_single<16>(wave, lane, q, c16, w1, l1, r1)); }
@@ -1866,7 +1859,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     /* the 16x16 CU's candidates (their jobs ran in the previous round): twelve per job wavefront, any wavefront will do */
     if (m == 1) hv_bin_own(S, im, c16, 12 * w1, hv_min(12, 70 - 12 * w1));
     if (k16 == 1 && m == 3) hv_bin_own(S, im, c32, 12 * w1, hv_min(12, 70 - 12 * w1));    /* the 32x32 CU's: its last jobs ran in round (1,2) */
-    hv_run_engines(S, im, (m >= 2 ? 2 : 0) | (k16 >= 2 ? 4 : 0), &S.nxn_busy, 6, w1, tb8, tc8);
+    hv_run_engines(S, im, (m >= 2 ? 2 : 0) | (k16 >= 2 ? 4 : 0), &S.nxn_busy, 6, w1);
 }
 
 static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, HevceRecord *rec, int32_t *dump) {
