@@ -1,4 +1,4 @@
-"""Randomised parity sweep (tools/gpu_stress.py): pictures of random size / content class / qpd6 in one batch, repeated
+"""Randomised parity sweep (tests/tools/gpu_stress.py): pictures of random size / content class / qpd6 in one batch, repeated
 launches, every stream and reconstruction against the oracle.  The kernel's wavefronts hand work to each other through
 LDS flags and idle-time riding, so its internal timing varies from launch to launch; this covers what fixed goldens cannot."""
 import os
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [11, 12])
 def test_random_pictures_match_oracle_over_repeated_launches(seed):
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import gpu_stress
     res = gpu_stress.sweep(72, seed, 3)
     assert res["mismatches"] == 0, res

@@ -57,6 +57,15 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".h", ".hip", ".cpp", ".c", ".py", "Makefile", ".map")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle/" not in txt and "hevce_oracle" not in txt and "orc_" not in txt, os.path.join(dp, f)
+    # the probes and utilities under tools/ and the helpers at the repo root measure the product: no oracle there either
+    # (checkers that use it live under tests/tools/; bench.py's cpu_baseline leg and __graft_entry__.smoke() are the two
+    # places outside tests/ that may, by contract)
+    import re
+    for f in [os.path.join(ROOT, "tools", n) for n in os.listdir(os.path.join(ROOT, "tools"))] + \
+             [os.path.join(ROOT, n) for n in ("hevce_pkg.py", "hevce_workload.py")]:
+        if f.endswith((".py", ".hip")):
+            txt = open(f, errors="ignore").read()
+            assert not re.search(r"\bimport orc\b|\borc\.|hevce_oracle|[\"']oracle[\"']", txt), f
 
 
 def test_tile_grid_and_tile_entry_point_without_gpu(hevce):

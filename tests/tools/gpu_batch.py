@@ -2,7 +2,7 @@
 """Batch throughput on one GPU: N independent pictures (one workgroup each) in ONE launch -- BASELINE.json configs[2]'s
 shape on a single GPU (default 256 x 1920x1080, qpd6=2), checked by a sample of streams against the oracle."""
 import os, sys, time, json, hashlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import hevce_pkg, hevce_workload as wl

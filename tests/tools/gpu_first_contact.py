@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Staged first-contact probe: every stage is logged with a timestamp and flushed, so a hang can be located."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 t0 = time.time()
 def log(*a):
     print(f"[{time.time()-t0:7.2f}s]", *a, flush=True)
@@ -10,7 +10,7 @@ log("numpy ok")
 import hevce_pkg, hevce_workload as wl
 hevce = hevce_pkg.load()
 log("lib loaded", hevce.lib().hevce_version(), "devices", hevce.device_count())
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
 import orc
 for (h, w) in [(32, 32), (64, 96), (256, 256)]:
     img = wl.gen_g2(h, w, 16)

@@ -3,7 +3,7 @@
 REAL reference (oracle/_ref, compiled from the reference sources, one CPU core, ~2 minutes): streams and reconstructions
 must be byte-identical.  Test infrastructure; prints one JSON line (kept under profiles/)."""
 import hashlib, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import hevce_pkg, hevce_workload as wl, orc

@@ -4,7 +4,7 @@ C ABI, every stream and reconstruction compared with the oracle (CPU restatement
 wavefronts hand work to each other through LDS flags and idle-time riding, i.e. its timing varies from launch to launch:
 this sweep is there to catch what a fixed set of goldens cannot.  usage: gpu_stress.py [n_pictures] [seed] [repeats]"""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import hevce_pkg, hevce_workload as wl, orc

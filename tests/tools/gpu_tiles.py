@@ -5,7 +5,7 @@ picture resident in HBM (hevce_job_set_device_window).  A sample of tiles is che
 that window stored as its own picture -- the only definition of bit-exactness a tiled picture has (the reference crops
 at 8192x8192).   usage: gpu_tiles.py [size] [tile] [tiles-to-check]"""
 import os, sys, time, json, hashlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import torch

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Function-level parity on the GPU: TU pipeline of all 35 modes vs the oracle, per size / qpd6."""
 import os, sys, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import hevce_pkg, orc

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run one library variant (HEVCE_LIB) on a few images and compare with the oracle."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import hevce_pkg, hevce_workload as wl, orc
