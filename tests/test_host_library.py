@@ -81,3 +81,25 @@ def test_tile_grid_and_tile_entry_point_without_gpu(hevce):
     if hevce.device_count() <= 0:
         with pytest.raises(hevce.HevceError):
             hevce.encode_tiles(img, 2, 32, 32)
+
+
+def test_partition_of_a_batch_over_ranks(hevce):
+    """longest-processing-time-first on CTU count; every picture exactly once, deterministic, balanced to within
+    one picture; a single rank keeps everything; pictures above 8192 count as cropped"""
+    import importlib
+    sh = importlib.import_module(hevce.__name__ + ".sharding")
+    assert sh.ctus(1080, 1920) == 2040 and sh.ctus(1, 1) == 1 and sh.ctus(9000, 100) == 256 * 4
+    rng = np.random.RandomState(4)
+    sizes = [(int(rng.randint(1, 2200)), int(rng.randint(1, 4000))) for _ in range(97)]
+    for n in (1, 2, 3, 8):
+        shards = sh.partition_lpt(sizes, n)
+        assert sorted(i for s in shards for i in s) == list(range(97)) and shards == sh.partition_lpt(sizes, n)
+        loads = [sum(sh.ctus(*sizes[i]) for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(sh.ctus(*s) for s in sizes)
+        for s in shards:
+            assert [sh.ctus(*sizes[i]) for i in s] == sorted((sh.ctus(*sizes[i]) for i in s), reverse=True)
+    equal = sh.partition_lpt([(1080, 1920)] * 1024, 8)
+    assert all(len(s) == 128 for s in equal) and equal[0][:2] == [0, 8]
+    assert sh.waves([(1080, 1920)] * 300) == (2, 2 * 2040) and sh.waves([]) == (0, 0)
+    with pytest.raises(ValueError):
+        sh.partition_lpt(sizes, 0)

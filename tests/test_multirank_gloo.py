@@ -52,3 +52,52 @@ def test_two_ranks_gather_streams():
         assert p.exitcode == 0
     want = [hashlib.sha256(orc.encode(wl.gen_g2(64, 96, 16, seed=0x1234ABCD + r), 2)[0]).hexdigest() for r in range(2)]
     assert got == want and got[0] != got[1]
+
+
+def _batch_worker(rank, world, port, q):
+    """the sharding + collection logic of tools/dist_batch.py (LPT partition, no data-path collective, one
+    all_gather_object of (index, length, sha) tables), with the oracle standing in for the device"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import importlib
+    import torch.distributed as dist
+    import hevce_pkg
+    import hevce_workload as wl
+    import orc
+    sharding = importlib.import_module(hevce_pkg.load().__name__ + ".sharding")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = [(16 + 8 * (i % 5), 24 + 16 * (i % 3)) for i in range(11)]
+    mine = sharding.partition_lpt(sizes, world)[rank]
+    out = []
+    for i in mine:
+        s, _ = orc.encode(wl.gen_g2(sizes[i][0], sizes[i][1], 16, seed=0x1234ABCD + i), 2)
+        out.append((i, len(s), hashlib.sha256(s).hexdigest()))
+    table = [None] * world
+    dist.all_gather_object(table, out)
+    dist.barrier()
+    if rank == 0:
+        q.put(sorted(x for part in table for x in part))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_a_batch():
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hevce_workload as wl
+    import orc
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = [(16 + 8 * (i % 5), 24 + 16 * (i % 3)) for i in range(11)]
+    want = []
+    for i, (h, w) in enumerate(sizes):
+        s, _ = orc.encode(wl.gen_g2(h, w, 16, seed=0x1234ABCD + i), 2)
+        want.append((i, len(s), hashlib.sha256(s).hexdigest()))
+    assert got == want
