@@ -901,6 +901,45 @@ template <> struct HvTm<32> { static HD const int *f() { return hv_tm.f32; } sta
 
 struct HvTuOut { int sse, last, cbf; u64 cgsig; };          /* block-wide values, identical in all lanes of a slot */
 
+/* The 8/16/32-point core transforms as partial butterflies.  Rows of even frequency are symmetric, rows of odd frequency
+   antisymmetric, and the even rows of the N-point matrix are the N/2-point matrix (hv_basis): N*N/3 multiplications
+   instead of N*N, with exactly the reference's integer sums (it multiplies the whole matrix out, HEVCe.c:469-516; integer
+   addition is associative, nothing here can overflow: |inputs| < 2^16, |coefficients| <= 90).
+   x[0..M) = the M inputs (forward) / the inputs of frequency 0, S, 2S, ... (inverse, S = N/M); all indices compile-time. */
+template <int N, int M> struct HvBfly {
+    enum { S = N / M, H = M / 2 };
+    /* forward: out[f * S] for f = 0..M-1 from x (destroyed) */
+    static HD void fwd(int *x, int *out) {
+        int o[H];
+#pragma unroll
+        for (int k = 0; k < H; k++) { const int a = x[k], b = x[M - 1 - k]; x[k] = a + b; o[k] = a - b; }
+#pragma unroll
+        for (int f = 1; f < M; f += 2) {
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < H; k++) acc += hv_mul24(hv_basis(f * S * (32 / N), k * 1), o[k]);
+            out[f * S] = acc;
+        }
+        HvBfly<N, H>::fwd(x, out);
+    }
+    /* inverse: out[0..M) (sample positions of the M-point transform) from the inputs in[f * S], f = 0..M-1 */
+    static HD void inv(const int *in, int *out) {
+        int e[H];
+        HvBfly<N, H>::inv(in, e);
+#pragma unroll
+        for (int n = 0; n < H; n++) {
+            int acc = 0;
+#pragma unroll
+            for (int f = 1; f < M; f += 2) acc += hv_mul24(hv_basis(f * S * (32 / N), n), in[f * S]);
+            out[n] = e[n] + acc; out[M - 1 - n] = e[n] - acc;
+        }
+    }
+};
+template <int N> struct HvBfly<N, 1> {
+    static HD void fwd(int *x, int *out) { out[0] = 64 * x[0]; }
+    static HD void inv(const int *in, int *out) { out[0] = 64 * in[0]; }
+};
+
 /* reconstructed sample at CTU-relative (yy,xx).  Inside the CU under trial it comes from the candidate's own partial
    reconstruction: `inner` is either the full cu_n x cu_n block (NxN sub-search) or, when `edges` is set, the chain's edge
    store [4][H]: right columns of sub-blocks 0 and 2, bottom rows of sub-blocks 0 and 1 -- the only inner samples a later
@@ -1055,12 +1094,19 @@ static HD HvTuOut hv_tu_job(int wave, int lane, int q,
         constexpr int s1 = LG - 1;
 #pragma unroll
         for (int k = 0; k < N; k++) v[k] = scr[k * RS + j];
-        const int *tab = HvTm<N>::f();
-        for (int i = 0; i < N; i++) {
-            int acc = 1 << s1 >> 1;
+        if constexpr (N >= 8) {
+            int out[N];
+            HvBfly<N, N>::fwd(v, out);
 #pragma unroll
-            for (int k = 0; k < N; k++) acc += hv_mul24(tab[i * N + k], v[k]);
-            scr[i * RS + j] = (short)(acc >> s1);
+            for (int i = 0; i < N; i++) scr[i * RS + j] = (short)((out[i] + (1 << s1 >> 1)) >> s1);
+        } else {
+            const int *tab = HvTm<N>::f();
+            for (int i = 0; i < N; i++) {
+                int acc = 1 << s1 >> 1;
+#pragma unroll
+                for (int k = 0; k < N; k++) acc += hv_mul24(tab[i * N + k], v[k]);
+                scr[i * RS + j] = (short)(acc >> s1);
+            }
         }
     }
     WAVE_SYNC();
@@ -1074,15 +1120,27 @@ static HD HvTuOut hv_tu_job(int wave, int lane, int q,
 #pragma unroll
         for (int k = 0; k < N; k++) v[k] = scr[j * RS + k];
         const int *tab = HvTm<N>::f();
+        if constexpr (N >= 8) {
+            /* all N coefficients of the row at once; they wait in the row's own scratch line (16 bits: |coefficient| <= 32640
+               for 8-bit samples, the bound the first pass already relies on) until their 4x4 group's turn */
+            int out[N];
+            HvBfly<N, N>::fwd(v, out);
+#pragma unroll
+            for (int i = 0; i < N; i++) scr[j * RS + i] = (short)((out[i] + (1 << s2 >> 1)) >> s2);
+        }
         for (int g = 0; g < N / 4; g++) {
             int lv[4], sum = 0;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int cidx = g * 4 + e;
-                int acc = 1 << s2 >> 1;
+                int coef;
+                if constexpr (N >= 8) coef = scr[j * RS + cidx];
+                else {
+                    int acc = 1 << s2 >> 1;
 #pragma unroll
-                for (int k = 0; k < N; k++) acc += hv_mul24(tab[cidx * N + k], v[k]);
-                const int coef = acc >> s2;
+                    for (int k = 0; k < N; k++) acc += hv_mul24(tab[cidx * N + k], v[k]);
+                    coef = acc >> s2;
+                }
                 int d;
                 const int mag = hv_quant1(q, sh, dsh, hv_abs(coef), d);
                 lv[e] = coef < 0 ? -mag : mag;
@@ -1129,12 +1187,19 @@ static HD HvTuOut hv_tu_job(int wave, int lane, int q,
     {
 #pragma unroll
         for (int k = 0; k < N; k++) v[k] = scr[k * RS + j];
-        const int *tab = HvTm<N>::t();
-        for (int i = 0; i < N; i++) {
-            int acc = 64;
+        if constexpr (N >= 8) {
+            int out[N];
+            HvBfly<N, N>::inv(v, out);
 #pragma unroll
-            for (int k = 0; k < N; k++) acc += hv_mul24(tab[i * N + k], v[k]);
-            scr[i * RS + j] = (short)hv_clip16(acc >> 7);
+            for (int i = 0; i < N; i++) scr[i * RS + j] = (short)hv_clip16((out[i] + 64) >> 7);
+        } else {
+            const int *tab = HvTm<N>::t();
+            for (int i = 0; i < N; i++) {
+                int acc = 64;
+#pragma unroll
+                for (int k = 0; k < N; k++) acc += hv_mul24(tab[i * N + k], v[k]);
+                scr[i * RS + j] = (short)hv_clip16(acc >> 7);
+            }
         }
     }
     WAVE_SYNC();
@@ -1144,14 +1209,20 @@ static HD HvTuOut hv_tu_job(int wave, int lane, int q,
 #pragma unroll
         for (int k = 0; k < N; k++) v[k] = scr[j * RS + k];
         const int *tab = HvTm<N>::t();
+        int out[N];
+        if constexpr (N >= 8) HvBfly<N, N>::inv(v, out);
+#pragma unroll
         for (int x4 = 0; x4 < N; x4 += 4) {                      /* four samples = one 32-bit store */
             unsigned pk = 0;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int x = x4 + e;
                 int acc = 2048;
+                if constexpr (N >= 8) acc += out[x];
+                else {
 #pragma unroll
-                for (int k = 0; k < N; k++) acc += hv_mul24(tab[x * N + k], v[k]);
+                    for (int k = 0; k < N; k++) acc += hv_mul24(tab[x * N + k], v[k]);
+                }
                 const int r = hv_clip8(hv_clip16(acc >> 12) + pred[j * N + x]);
                 const int d = (int)S.org[ty + j][tx + x] - r;
                 sse += d * d;
