@@ -1918,11 +1918,18 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         if (w1 < 5) { HV_JOBT(10, hv_job_chain<8>(wave, lane, q, c16, w1, l1, r1)); HV_JOBT(11, hv_job_single<16>(wave, lane, q, c16, w1, l1, r1)); }
         else for (int j = 5; j < 9; j++) HV_JOBT(11, hv_job_single<16>(wave, lane, q, c16, j, l1, r1));
     } else if (k16 < 2 && !(k16 == 1 && m == 3)) {
-        /* 32x32: 9 chains (4 modes each, ~180 k cycles) and 18 single TUs (2 modes each, ~160 k): one per work slot in the
-           five phases (k16, m) = (0,1) (0,2) (0,3) (1,1) (1,2); a second one would outlast the NxN chain (~270 k) */
-        const int idx = (k16 * 3 + m - 1) * 6 + w1;
-        if (idx < 9) HV_JOBT(12, hv_job_chain<16>(wave, lane, q, c32, idx, l2, r2));
-        else if (idx < 27) HV_JOBT(13, hv_job_single<32>(wave, lane, q, c32, idx - 9, l2, r2));
+        /* 32x32: 9 chains (4 modes each, ~150 k cycles) and 18 single TUs (2 modes each, ~75 k): one per work slot in the
+           five phases (k16, m) = (0,1) (0,2) (0,3) (1,1) (1,2).  The two phases with m == 1 also carry the 16x16 candidates'
+           binarisation (~53 k): they get the short jobs, the chains go to (0,2) and (0,3) */
+        const int r5 = k16 * 3 + m - 1;
+        int chain = -1, single = -1;
+        if (r5 == 0) single = w1;
+        else if (r5 == 1) chain = w1;
+        else if (r5 == 2) { if (w1 < 3) chain = 6 + w1; else single = 3 + w1; }
+        else if (r5 == 3) single = 9 + w1;
+        else if (w1 < 3) single = 15 + w1;
+        if (chain >= 0) HV_JOBT(12, hv_job_chain<16>(wave, lane, q, c32, chain, l2, r2));
+        if (single >= 0) HV_JOBT(13, hv_job_single<32>(wave, lane, q, c32, single, l2, r2));
     }
     /* whatever time the NxN chain still takes: the candidates of the enclosing CUs that are already prepared ride on, twelve
        lanes per CU level and job wavefront, until wavefront 0 clears S.nxn_busy (16x16 candidates exist from their CU's
