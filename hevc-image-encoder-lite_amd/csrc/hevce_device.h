@@ -150,6 +150,7 @@ struct HvWaveScr {                                          /* private to one wa
     u8    pred[64 * 32];                                    /* [slot][row][N] prediction                        */
     u8    bord[672];                                        /* [slot][raw|smoothed][4N+4] reference samples     */
     u8    edge[256];                                        /* [slot][4][H] TU-split chains: right columns of sub-blocks 0,2 and bottom rows of 0,1 */
+    u8    line[256];                                        /* [slot][3N+2] angular modes: the mode's reference line r(-N..2N) */
 };
 
 struct alignas(16) HvLds {
@@ -1031,6 +1032,26 @@ static HD HvTuOut hv_tu_job(int wave, int lane, int q,
     int dcsum = braw[1 + j] + braw[1 + 2 * N + j];
     for (int s = 1; s < N; s <<= 1) dcsum += hv_shfl_xor(dcsum, s);
     WAVE_SYNC();
+    /* angular modes: the slot's reference line r(k), k = -N..2N, laid out once by its N lanes (r(k>0) main side, r(0) corner,
+       r(k<0) the side samples projected through the inverse angle [ref :353-364]); the pixel loop then only indexes it.
+       Every lane takes part (the other mode forms just do not read it): no wave-level step inside a per-mode branch */
+    u8 *line = W.line + slot * (3 * N + 2) + N;
+    {
+        const u8 *b = hv_smoothed(N, m) ? bsm : braw;
+        const bool horiz = m < 18;
+        const int inv = S.invang[m];
+        const u8 *mainr = horiz ? b + 1 : b + 1 + 2 * N, *sider = horiz ? b + 1 + 2 * N : b + 1;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const int k = e * N + j - N + 1;                     /* -N+1 .. 2N */
+            int v;
+            if (k > 0) v = mainr[k - 1];
+            else if (k == 0) v = b[0];
+            else v = sider[hv_min(hv_max(((128 - inv * k) >> 8) - 1, 0), 2 * N - 1)];   /* entries outside the projected range are never read */
+            line[k] = (u8)v;
+        }
+    }
+    WAVE_SYNC();
 
     HV_TUT(0);
     /* ---- prediction of column j  [ref HEVCe.c:262-381]; residual goes to scr, prediction to pred ---- */
@@ -1070,18 +1091,14 @@ static HD HvTuOut hv_tu_job(int wave, int lane, int q,
                 pred[i * N + j] = (u8)p; scr[i * RS + j] = (short)((int)S.org[ty + i][ox] - p);
             }
         } else {
-            /* angular: reference line r(k): k>0 main side, k==0 corner, k<0 side samples projected by the inverse angle */
+            /* angular: two neighbours on the mode's reference line, 1/32-sample weights  [ref :342-380] */
             const bool horiz = m < 18;
-            const int ang = S.ang[m], inv = S.invang[m];
-            const u8 *mainr = horiz ? l : a, *sider = horiz ? a : l;
+            const int ang = S.ang[m];
             for (int i = 0; i < N; i++) {
                 const int step = horiz ? j : i, along = horiz ? i : j;
                 const int off = ang * (step + 1), oi = off >> 5, of = off & 31;
-                int k1 = oi + along + 1, k2 = k1 + 1;
-                if (k2 > 2 * N) k2 = 2 * N;                 /* weight 0 there (modes 2 / 34): any in-range sample */
-                const int p1 = k1 > 0 ? mainr[k1 - 1] : (k1 == 0 ? c : sider[((128 - inv * k1) >> 8) - 1]);
-                const int p2 = k2 > 0 ? mainr[k2 - 1] : (k2 == 0 ? c : sider[((128 - inv * k2) >> 8) - 1]);
-                const int p = ((32 - of) * p1 + of * p2 + 16) >> 5;
+                const int k1 = oi + along + 1, k2 = hv_min(k1 + 1, 2 * N);   /* weight 0 at 2N+1 (modes 2 / 34): any in-range sample */
+                const int p = ((32 - of) * line[k1] + of * line[k2] + 16) >> 5;
                 pred[i * N + j] = (u8)p; scr[i * RS + j] = (short)((int)S.org[ty + i][ox] - p);
             }
         }
