@@ -30,7 +30,8 @@ hevce_test_tu_kernel(const unsigned char *org /*32x32*/, const unsigned char *nb
     for (int p = tid; p < 33 * 65; p += 64) S.rec[p / 65][HV_RX - 1 + p % 65] = nbr[p];
     if (tid == 0) S.trace = nullptr;
     __syncthreads();
-    /* the single-wave block has no thread 64/128/300: build the scan tables and contexts here */
+    /* the single-wave block has no thread 64/128/300/384: build the angle tables, scan tables and contexts here */
+    if (tid < 35) { S.ang[tid] = hv_ang[tid]; S.invang[tid] = hv_invang[tid]; }
     if (tid == 0) {
         int k = 0;
         for (int d = 0; d <= 6; d++)
@@ -74,6 +75,7 @@ hevce_test_chain_kernel(const unsigned char *org, const unsigned char *nbr, int 
     hv_init_tables(S, q, tid);
     for (int p = tid; p < 1024; p += 64) S.org[p >> 5][p & 31] = org[p];
     for (int p = tid; p < 33 * 65; p += 64) S.rec[p / 65][HV_RX - 1 + p % 65] = nbr[p];
+    if (tid < 35) { S.ang[tid] = hv_ang[tid]; S.invang[tid] = hv_invang[tid]; }   /* no thread 384 in a single-wave block */
     if (tid == 0) {
         S.trace = nullptr;
         int k = 0;

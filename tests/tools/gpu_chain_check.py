@@ -43,17 +43,27 @@ def oracle_chain(org, nbr, n, q, m, fl):
     return np.concatenate(levs), buf[1:1 + n, 1:1 + n].copy(), sse_t
 
 
-rng = np.random.RandomState(3)
-for n in (8, 16, 32):
-    for q in (2, 0, 4):
-        for fl in ((0, 0, 0, 0), (1, 0, 1, 1), (1, 1 if n < 32 else 0, 1, 0)):
-            org = (rng.randint(-16, 17, (32, 32)) + 200).clip(0, 255).astype(np.uint8) if q == 2 else rng.randint(0, 256, (32, 32)).astype(np.uint8)
-            nbr = rng.randint(0, 256, (33, 65)).astype(np.uint8)
-            lev = np.zeros((35, 1024), np.int16); rec = np.zeros((35, 1024), np.uint8); info = np.zeros((35, 16), np.int32)
-            assert L.hevce_test_chain(org.ctypes.data_as(vp), nbr.ctypes.data_as(vp), n, q, *fl, lev.ctypes.data_as(vp), rec.ctypes.data_as(vp), info.ctypes.data_as(vp)) == 0
-            bad = []
-            for m in range(35):
-                ol, orc_, osse = oracle_chain(org, nbr, n, q, m, fl)
-                nl = int((lev[m, :n * n] != ol).sum()); nr = int((rec[m, :n * n].reshape(n, n) != orc_).sum())
-                if nl or nr or info[m, 0] != osse: bad.append((m, nl, nr, int(info[m, 0]), osse))
-            print("chain n", n, "q", q, "flags", fl, "bad:", bad[:5], "..." if len(bad) > 5 else "", flush=True)
+def check(seed=3, extreme=False):
+    """returns [(n, q, flags, bad modes)] for every case with a mismatch; extreme: samples only 0 / 255"""
+    rng = np.random.RandomState(seed)
+    failures = []
+    for n in (8, 16, 32):
+        for q in (2, 0, 4, 1, 3):
+            for fl in ((0, 0, 0, 0), (1, 0, 1, 1), (1, 1 if n < 32 else 0, 1, 0)):
+                org = (rng.randint(-16, 17, (32, 32)) + 200).clip(0, 255).astype(np.uint8) if q == 2 else rng.randint(0, 256, (32, 32)).astype(np.uint8)
+                nbr = rng.randint(0, 256, (33, 65)).astype(np.uint8)
+                if extreme: org = (rng.randint(0, 2, (32, 32)) * 255).astype(np.uint8); nbr = (rng.randint(0, 2, (33, 65)) * 255).astype(np.uint8)
+                lev = np.zeros((35, 1024), np.int16); rec = np.zeros((35, 1024), np.uint8); info = np.zeros((35, 16), np.int32)
+                assert L.hevce_test_chain(org.ctypes.data_as(vp), nbr.ctypes.data_as(vp), n, q, *fl, lev.ctypes.data_as(vp), rec.ctypes.data_as(vp), info.ctypes.data_as(vp)) == 0
+                bad = []
+                for m in range(35):
+                    ol, orc_, osse = oracle_chain(org, nbr, n, q, m, fl)
+                    nl = int((lev[m, :n * n] != ol).sum()); nr = int((rec[m, :n * n].reshape(n, n) != orc_).sum())
+                    if nl or nr or info[m, 0] != osse: bad.append((m, nl, nr, int(info[m, 0]), osse))
+                if bad: failures.append((n, q, fl, bad[:5]))
+    return failures
+
+
+if __name__ == "__main__":
+    for ext in (False, True):
+        print("extreme" if ext else "random", "failures:", check(3, ext), flush=True)

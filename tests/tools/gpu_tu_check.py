@@ -6,29 +6,42 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import hevce_pkg, orc
 hevce = hevce_pkg.load(); L = hevce.lib(); O = orc.lib()
-rng = np.random.RandomState(1)
 vp = C.c_void_p
-for n in (4, 8, 16, 32):
-    for q in (0, 2, 4):
-        org = rng.randint(0, 256, (32, 32)).astype(np.uint8)
-        if q == 2: org = (rng.randint(-16, 17, (32, 32)) + 128 + 80).clip(0, 255).astype(np.uint8)
-        nbr = rng.randint(0, 256, (33, 65)).astype(np.uint8)
-        lev = np.zeros((35, 1024), np.int16); rec = np.zeros((35, 1024), np.uint8); info = np.zeros((35, 4), np.int32)
-        lb = 1 if n < 32 else 0      # a 32x32 block at the CTU origin has no left-below rows
-        rc = L.hevce_test_tu(org.ctypes.data_as(vp), nbr.ctypes.data_as(vp), n, q, 1, lb, 1, 1, lev.ctypes.data_as(vp), rec.ctypes.data_as(vp), info.ctypes.data_as(vp))
-        assert rc == 0
-        corner = int(nbr[0, 0])
-        left = np.ascontiguousarray(nbr[1:1 + 2 * n, 0]) if lb else np.ascontiguousarray(np.concatenate([nbr[1:1 + n, 0], np.full(n, nbr[n, 0], np.uint8)]))
-        above = np.ascontiguousarray(nbr[0, 1:1 + 2 * n])
-        bad = []
-        for m in range(35):
-            olev = np.zeros((n, n), np.int32); orec = np.zeros((n, n), np.uint8)
-            blk = np.ascontiguousarray(org[:n, :n])
-            sse = O.orc_tu_trial(q, n, m, corner, left.ctypes.data_as(vp), above.ctypes.data_as(vp), blk.ctypes.data_as(vp), olev.ctypes.data_as(vp), orec.ctypes.data_as(vp))
-            kind = 0
-            if n <= 8: kind = 1 if abs(m - 26) <= 4 else (2 if abs(m - 10) <= 4 else 0)
-            sc = np.zeros((n * n, 2), np.uint8); O.orc_scan(n, kind, sc.ctypes.data_as(vp))
-            oscan = olev[sc[:, 0], sc[:, 1]]
-            ok = (lev[m, :n * n] == oscan).all() and (rec[m, :n * n].reshape(n, n) == orec).all() and info[m, 0] == sse
-            if not ok: bad.append((m, int((lev[m, :n * n] != oscan).sum()), int((rec[m, :n * n].reshape(n, n) != orec).sum()), int(info[m, 0]), sse))
-        print("n", n, "q", q, "bad modes:", bad[:6], "..." if len(bad) > 6 else "", flush=True)
+
+
+def check(seed=1, extreme=False):
+  """returns [(n, q, bad modes)] for every (size, qpd6) with a mismatch; extreme: samples only 0 / 255 (the largest residuals
+  and transform sums 8-bit input can produce)"""
+  rng = np.random.RandomState(seed)
+  failures = []
+  for n in (4, 8, 16, 32):
+    for q in (0, 1, 2, 3, 4):
+          org = rng.randint(0, 256, (32, 32)).astype(np.uint8)
+          if q == 2 and not extreme: org = (rng.randint(-16, 17, (32, 32)) + 128 + 80).clip(0, 255).astype(np.uint8)
+          nbr = rng.randint(0, 256, (33, 65)).astype(np.uint8)
+          if extreme: org = (rng.randint(0, 2, (32, 32)) * 255).astype(np.uint8); nbr = (rng.randint(0, 2, (33, 65)) * 255).astype(np.uint8)
+          lev = np.zeros((35, 1024), np.int16); rec = np.zeros((35, 1024), np.uint8); info = np.zeros((35, 4), np.int32)
+          lb = 1 if n < 32 else 0      # a 32x32 block at the CTU origin has no left-below rows
+          rc = L.hevce_test_tu(org.ctypes.data_as(vp), nbr.ctypes.data_as(vp), n, q, 1, lb, 1, 1, lev.ctypes.data_as(vp), rec.ctypes.data_as(vp), info.ctypes.data_as(vp))
+          assert rc == 0
+          corner = int(nbr[0, 0])
+          left = np.ascontiguousarray(nbr[1:1 + 2 * n, 0]) if lb else np.ascontiguousarray(np.concatenate([nbr[1:1 + n, 0], np.full(n, nbr[n, 0], np.uint8)]))
+          above = np.ascontiguousarray(nbr[0, 1:1 + 2 * n])
+          bad = []
+          for m in range(35):
+              olev = np.zeros((n, n), np.int32); orec = np.zeros((n, n), np.uint8)
+              blk = np.ascontiguousarray(org[:n, :n])
+              sse = O.orc_tu_trial(q, n, m, corner, left.ctypes.data_as(vp), above.ctypes.data_as(vp), blk.ctypes.data_as(vp), olev.ctypes.data_as(vp), orec.ctypes.data_as(vp))
+              kind = 0
+              if n <= 8: kind = 1 if abs(m - 26) <= 4 else (2 if abs(m - 10) <= 4 else 0)
+              sc = np.zeros((n * n, 2), np.uint8); O.orc_scan(n, kind, sc.ctypes.data_as(vp))
+              oscan = olev[sc[:, 0], sc[:, 1]]
+              ok = (lev[m, :n * n] == oscan).all() and (rec[m, :n * n].reshape(n, n) == orec).all() and info[m, 0] == sse
+              if not ok: bad.append((m, int((lev[m, :n * n] != oscan).sum()), int((rec[m, :n * n].reshape(n, n) != orec).sum()), int(info[m, 0]), sse))
+          if bad: failures.append((n, q, bad[:6]))
+  return failures
+
+
+if __name__ == "__main__":
+    for ext in (False, True):
+        print("extreme" if ext else "random", "failures:", check(1, ext), flush=True)
