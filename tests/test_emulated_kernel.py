@@ -25,3 +25,16 @@ def test_emulated_kernel_matches_golden(path):
     stream = bytes(c["stream"])
     assert len(emu.analyse.payload) > 0 and stream.endswith(emu.analyse.payload)
     assert len(stream) - len(emu.analyse.payload) in range(70, 100)
+
+
+@pytest.mark.parametrize("q", [0, 2, 4])
+def test_emulated_kernel_on_black_and_white_noise(orc, q):
+    """a picture of 0 / 255 samples only: the largest residuals, transform sums (the 16-bit staging of the butterflies relies on
+    |coefficient| <= 32640) and level magnitudes 8-bit input can produce -- against the oracle, one 32x32 and 16x16 CU deep"""
+    import emu
+    img = (np.random.RandomState(40 + q).randint(0, 2, (40, 72)) * 255).astype(np.uint8)
+    rec, rcon, st = emu.analyse(img, q)
+    orec, orcon, ost = orc.analyse(img, q)
+    assert np.array_equal(rcon, orcon) and np.array_equal(st, ost) and np.array_equal(rec, orec)
+    stream, _ = orc.encode(img, q)
+    assert stream.endswith(emu.analyse.payload) and len(emu.analyse.payload) > 0
