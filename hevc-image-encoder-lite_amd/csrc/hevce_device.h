@@ -875,8 +875,15 @@ static HD int hv_quant1(int q, int sh, int dsh, int av, int &d) {
     d = (av > 0x1ffff) ? dmax : hv_min((av & 0x1ffff) << 14, dmax);
     const int lv0 = hv_clip16((d + half) >> sh);
     int best = HV_I32MAX, pick = 0;
+    /* The third candidate can only win when the reference's saturating square is reached, i.e. for qpd6 = 4: with
+       E = 2^(sh - dsh) = 2^(11 + q) the scaled distances of candidates 1 and 2 are e1 in [E/2, 3E/2) and e2 = e1 + E, so their
+       distortions differ by at least (2 e1 E + E^2) / 128 >= E^2 / 64, weighted 11, 11, 11, 5 for q = 0..3: >= 7.2e5, 2.9e6,
+       1.15e7, 2.1e7 -- an order of magnitude above the largest rate step times its weight (70000 x 1, 4, 16, 29).  For
+       q = 4 both squares can saturate to the same value and the cheaper level wins. */
+    const int ncand = (q >= 4) ? 3 : 2;
 #pragma unroll
     for (int t = 0; t < 3; t++) {
+        if (t >= ncand) break;
         const int lv = hv_max(lv0 - t, 0);
         const int e = hv_abs(d - (lv << sh)) >> dsh;
         const int dist = ((e < 46340) ? (int)hv_umul24((unsigned)e, (unsigned)e) : HV_I32MAX) >> 7;   /* 46339^2 < 2^31 */
