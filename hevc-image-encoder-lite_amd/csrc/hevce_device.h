@@ -1365,7 +1365,7 @@ static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int 
 #pragma unroll
             for (int al = 0; al < 4; al++) {
                 const int k1 = oi + al + 1;
-                const int v = ((32 - of) * line[k1] + of * line[k1 + 1] + 16) >> 5;
+                const int v = (hv_mul24(32 - of, line[k1]) + hv_mul24(of, line[k1 + 1]) + 16) >> 5;
                 p[al * 4 + st] = horiz ? v : p[al * 4 + st];
                 p[st * 4 + al] = horiz ? p[st * 4 + al] : v;
             }
@@ -1400,14 +1400,14 @@ static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int 
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) t[i * 4 + j] = (D[i * 4] * r[j] + D[i * 4 + 1] * r[4 + j] + D[i * 4 + 2] * r[8 + j] + D[i * 4 + 3] * r[12 + j] + 1) >> 1;
+        for (int j = 0; j < 4; j++) t[i * 4 + j] = (hv_mul24(D[i * 4], r[j]) + hv_mul24(D[i * 4 + 1], r[4 + j]) + hv_mul24(D[i * 4 + 2], r[8 + j]) + hv_mul24(D[i * 4 + 3], r[12 + j]) + 1) >> 1;   /* 24-bit multiplies throughout: |operands| < 2^16 x 2^7; a plain product becomes a shift-and-add chain or a quarter-rate 32-bit multiply */
     const int sh = 19 + q, thr = 9 << sh >> 2, qsh = 5 + q;
     int lv[16], sum = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int coef = (t[i * 4] * D[j * 4] + t[i * 4 + 1] * D[j * 4 + 1] + t[i * 4 + 2] * D[j * 4 + 2] + t[i * 4 + 3] * D[j * 4 + 3] + 128) >> 8;
+            const int coef = (hv_mul24(t[i * 4], D[j * 4]) + hv_mul24(t[i * 4 + 1], D[j * 4 + 1]) + hv_mul24(t[i * 4 + 2], D[j * 4 + 2]) + hv_mul24(t[i * 4 + 3], D[j * 4 + 3]) + 128) >> 8;
             int d;
             const int mag = hv_quant1(q, sh, 8, hv_abs(coef), d);
             lv[i * 4 + j] = coef < 0 ? -mag : mag;
@@ -1443,16 +1443,16 @@ static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int 
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) t[i * 4 + j] = hv_clip16((D[i] * r[j] + D[4 + i] * r[4 + j] + D[8 + i] * r[8 + j] + D[12 + i] * r[12 + j] + 64) >> 7);
+        for (int j = 0; j < 4; j++) t[i * 4 + j] = hv_clip16((hv_mul24(D[i], r[j]) + hv_mul24(D[4 + i], r[4 + j]) + hv_mul24(D[8 + i], r[8 + j]) + hv_mul24(D[12 + i], r[12 + j]) + 64) >> 7);
     int sse = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int res = hv_clip16((t[i * 4] * D[j] + t[i * 4 + 1] * D[4 + j] + t[i * 4 + 2] * D[8 + j] + t[i * 4 + 3] * D[12 + j] + 2048) >> 12);
+            const int res = hv_clip16((hv_mul24(t[i * 4], D[j]) + hv_mul24(t[i * 4 + 1], D[4 + j]) + hv_mul24(t[i * 4 + 2], D[8 + j]) + hv_mul24(t[i * 4 + 3], D[12 + j]) + 2048) >> 12);
             const int rc = hv_clip8(res + p[i * 4 + j]);
             const int dd = (int)S.org[ty + i][tx + j] - rc;
-            sse += dd * dd;
+            sse += hv_mul24(dd, dd);
             p[i * 4 + j] = rc;
         }
     {
