@@ -1904,11 +1904,7 @@ static HD void hv_emit_finish(HvLds &S, const HevceImageDesc &im) {
         its first child (m == 0), the 27 jobs of the 32x32 CU one per slot in rounds (0,1) (0,2) (0,3) (1,1) (1,2);
      3. in the time the NxN chain still takes, the prepared candidates of the enclosing CUs ride on.
    The schedule is static and wave-uniform (SGPRs): no lane-dependent control flow may surround the jobs (wave shuffles). */
-#ifdef HEVCE_PROF_JOBS
-#define HV_JOBT(slot, call) do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); call; if (lane == 0) S.prof2[8 + (slot)] += __builtin_amdgcn_s_memtime() - t0_; } while (0)
-#else
 #define HV_JOBT(slot, call) call
-#endif
 static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m, int ctu) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
     const int wv = hv_uni(wave);
