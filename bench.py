@@ -138,6 +138,16 @@ def main():
             traffic = round(json.load(f)["hbm_bytes_per_ctu"] * nctu)
     except Exception:
         traffic = None
+    # the bound that actually holds: VALU issue of the one compute unit a picture occupies -- from the committed
+    # instruction-mix PMC passes of this kernel (profiles/r01_pmc_instmix.json); informational, next to the mandated HBM figures
+    valu = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_instmix.json")) as f:
+            m = json.load(f)
+            valu = {"valu_issue_utilisation_of_the_cu": round(m["valu_issue_utilisation_of_the_cu"], 3),
+                    "valu_insts_per_ctu": round(m["valu_insts_per_ctu"]), "cu_cycles_per_ctu": round(m["cu_cycles_per_ctu"])}
+    except Exception:
+        valu = None
 
     if rank == 0:
         line = {
@@ -153,7 +163,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 9), "traffic": traffic,
                          "kernel": "hevce_analyse_kernel", "kernel_ms_avg": round(k_avg, 3),
                          "us_per_ctu": round(k_avg * 1e3 / nctu, 2),
-                         "note": "serial-dependency bound by construction (SURVEY 0.2): one picture = one workgroup chain"},
+                         "note": "serial-dependency bound by construction (SURVEY 0.2): one picture = one workgroup chain",
+                         "valu_issue": valu},
             "phases_ms": {"kernel": round(k_avg, 2), "d2h": round(float(np.mean(d2h_ms)), 2), "host_assembly": round(float(np.mean(writer_ms)), 2)},
             "stream_bytes": len(first), "stream_sha256": hashlib.sha256(first).hexdigest(),
         }
