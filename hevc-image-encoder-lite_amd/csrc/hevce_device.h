@@ -21,6 +21,7 @@
 #define HV_GLOBAL
 #define HV_LDSP
 #define HV_KEEP(x) do { } while (0)
+static inline unsigned hv_ldg_u32(const unsigned *p) { return *p; }
 #else
 #include <hip/hip_runtime.h>
 #define HD  __device__ __forceinline__
@@ -61,6 +62,7 @@ static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v
 static HD int  hv_clz_nz(unsigned v) { return __builtin_clz(v); }   /* v != 0: the bare instruction */
 static HD unsigned long long hv_ballot(int p) { return __ballot(p); }   /* one bit per active lane */
 static HD int  hv_clzll(unsigned long long v) { return __clzll((long long)v); }
+static HD unsigned hv_ldg_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   /* read at the L2: never a stale L1 line */
 #endif
 
 /* diagnostics: -DHEVCE_TRACE makes lane 0 of every wavefront publish its last checkpoint to host-pinned memory */
@@ -74,6 +76,9 @@ static HD int  hv_clzll(unsigned long long v) { return __clzll((long long)v); }
 #endif
 
 /* diagnostics: -DHEVCE_PROF accumulates shader-clock cycles per phase and CU size (thread 0, after the barriers) */
+#if defined(HEVCE_PROF) || defined(HEVCE_PROF_TU) || defined(HEVCE_PROF_NXN) || defined(HEVCE_PROF_ENG) || defined(HEVCE_PROF_BIN) || defined(HEVCE_PROF_JDUR) || defined(HEVCE_PROF_WAIT)
+#define HEVCE_ANYPROF 1
+#endif
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
 #define HV_PROF_T0()  unsigned long long pt_ = __builtin_amdgcn_s_memtime()
 #define HV_PROF2_T0() unsigned long long p2_ = __builtin_amdgcn_s_memtime()
@@ -203,12 +208,17 @@ struct alignas(16) HvLds {
     int winner, split_sse;
     int l0_active;                                          /* 8x8 candidates whose engines still run in this engine phase */
     int nxn_busy;                                           /* 1 while wavefront 0 walks the NxN chain of the current 8x8 CU */
-    /* device-side byte emission: the CTU's finished bytes are collected in coding order (a stack: a CU that ends up unsplit
-       rewinds to its mark and pushes its winner's); the previous CTU's are turned into stream bytes by wavefront 4 meanwhile */
-    int em_pos, em_mark[3], em_cnt[2], em_rd, em_slice;
-    int em_held, em_pending, em_zeros, em_n;                /* the emitting coder's byte state  [ref :797-806, 821-832, 859-879] */
+    /* the stream writer (wavefront 4, one lane): the exact byte-emitting coder of the FINAL syntax, one CTU behind the
+       analysis; it re-derives the bins of the previous CTU's decision record  [ref :797-933, 943-1340 for the chosen syntax] */
+    HevceCoderRegs wr;                                      /* range, low, nbits, pending bytes, held byte, zero run, bytes written */
+    u8  wr_ctx[HEVCE_NCTXP];
+    int wr_epb;                                             /* emulation-prevention bytes inserted while writing the current CTU */
+    u8  wr_linfo[8], wr_lmode[8], wr_ainfo[8];              /* CU size / mode of the 4x4 blocks left of and above the CTU being written */
+    alignas(16) HevceRecord wr_rec;                         /* its decision record, staged from HBM */
+#ifdef HEVCE_ANYPROF
     unsigned long long prof[3][8];
     unsigned long long prof2[32];                           /* HEVCE_PROF: inside the NxN job (tu jobs, tokenise, engine, select) */
+#endif
     int *trace;
     HvWaveScr ws[HV_NWAVES];
 };
@@ -367,7 +377,7 @@ template <typename ChunkP> static HD void hv_cod_replay(HvCod &c, ChunkP sink8, 
     }
 }
 /* context-coded bin; cx points at this trial's context byte  [ref :914-933] */
-static HD void hv_bin(const HvLds &S, HvCod &c, u8 *cx, int bin, HV_GLOBAL u16 *log = nullptr, int *nlog = nullptr) {
+static HD void hv_bin(const HvLds &S, HvCod &c, u8 *cx, int bin) {
     const int v = *cx, st = v >> 1, mps = v & 1;
     const int lps = (int)((S.lps4[st] >> (((c.range >> 6) & 3) << 3)) & 0xff);
     c.range -= lps;
@@ -381,7 +391,6 @@ static HD void hv_bin(const HvLds &S, HvCod &c, u8 *cx, int bin, HV_GLOBAL u16 *
         if (st < 62) *cx = (u8)(v + 2);
         if (c.range < 256) { c.low <<= 1; c.range <<= 1; c.nbits--; }
     }
-    if (log && c.nbits < 12) log[(*nlog)++] = (u16)(c.low >> (24 - c.nbits));   /* the byte hv_cod_carry is about to take */
     hv_cod_carry(c);
 }
 static HD void hv_bypass(HvCod &c, int bins, int len) {                                                    /* [ref :899-911] */
@@ -394,11 +403,10 @@ static HD void hv_bypass(HvCod &c, int bins, int len) {                         
         hv_cod_carry(c);
     }
 }
-static HD void hv_terminate(HvCod &c, int bin, HV_GLOBAL u16 *log = nullptr, int *nlog = nullptr) {              /* [ref :882-896] */
+static HD void hv_terminate(HvCod &c, int bin) {              /* [ref :882-896] */
     c.range -= 2;
     if (bin) { c.low = (c.low + (unsigned)c.range) << 7; c.range = 256; c.nbits -= 7; }
     else if (c.range < 256) { c.low <<= 1; c.range <<= 1; c.nbits--; }
-    if (log && c.nbits < 12) log[(*nlog)++] = (u16)(c.low >> (24 - c.nbits));
     hv_cod_carry(c);
 }
 
@@ -1604,11 +1612,11 @@ static HD void hv_job_sse(HvLds &S, int lane, const HvCu &cu) {
 }
 
 /* one context-coded bin on the committed coder (split_cu_flag = 1 of a parent)  [ref :1404] */
-static HD void hv_commit_bin(HvLds &S, const HevceImageDesc &im, int ctu, int ctx, int bin) {
+static HD void hv_commit_bin(HvLds &S, int ctx, int bin) {
     HvCod c;
     hv_cod_load(c, S.com);
     u8 tmp = S.com_ctx[ctx];
-    hv_bin(S, c, &tmp, bin, im.leadlog ? (HV_GLOBAL u16 *)im.leadlog + (ctu & 1) * HEVCE_LEADLOG_WORDS : nullptr, &S.em_pos);
+    hv_bin(S, c, &tmp, bin);
     S.com_ctx[ctx] = tmp;
     hv_cod_store(S.com, c);
 }
@@ -1788,17 +1796,12 @@ static HD void hv_run_engines(HvLds &S, const HevceImageDesc &im, int mask, int 
    wavefronts on one SIMD would take turns).  finish = 0: the 8x8 candidates run to their end, the candidates of the
    enclosing CUs ride along for as long as that takes (S.l0_active counts the 8x8 engines still running);
    finish = 1 (a 16x16 / 32x32 CU is decided): what the ride-along left runs to its end. */
-static HD void hv_emit_ctu(HvLds &S, const HevceImageDesc &im, int which, int limit);
 static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int finish, int ctu = 0) {
     const int wave = hv_tid() >> 6;
     HV_PROF_T0();
 #ifdef HEVCE_PROF_ENG
     const unsigned long long p0_ = __builtin_amdgcn_s_memtime();
 #endif
-    /* device-side byte emission: wavefront 4, idle otherwise, turns a slice of the PREVIOUS CTU's finished bytes into stream
-       bytes in each of the sixteen 8x8 engine phases -- one lane, a serial state machine; in one go it would outlast a whole
-       jobs phase, and it shares SIMD0's issue slots with wavefront 0, whose engines here have time to spare */
-    if (!finish && im.payload && ctu > 0 && hv_tid() == 4 * 64) hv_emit_ctu(S, im, (ctu - 1) & 1, S.em_slice);
     hv_run_engines(S, im, mask, finish ? nullptr : &S.l0_active, 4, wave < 4 ? wave : -1);
 #ifdef HEVCE_PROF_ENG
     const unsigned long long p1_ = __builtin_amdgcn_s_memtime();
@@ -1846,55 +1849,310 @@ static HD void hv_bin_own(HvLds &S, const HevceImageDesc &im, const HvCu cu, int
     HV_BINT(3);
 }
 
-/* Device-side byte emission  [ref CABACput :821-832, CABACupdate :859-879, CABACfinish :840-856].
-   The finished bytes of a CTU -- 9-bit values, carry + byte, in coding order -- become stream bytes: pending byte, runs of
-   0xff waiting for a carry, start-code emulation prevention.  One lane; the state lives in LDS between calls. */
-struct HvEmit { int held, pending, zeros, n; HV_GLOBAL u8 *out; };
-static HD void hv_em_put(HvEmit &e, int byte) {
-    byte &= 0xff;
-    if (e.zeros >= 2 && byte <= 3) { e.out[e.n++] = 3; e.zeros = 0; }
-    e.out[e.n++] = (u8)byte;
-    e.zeros = byte ? 0 : e.zeros + 1;
+/* --------------------------------------------------------------------------------------------- */
+/* The stream writer: ONE lane of wavefront 4 turns the decision record of the PREVIOUS CTU into the bytes of  */
+/* the slice data while the other wavefronts analyse the next one -- the reference's byte-emitting coder and syntax writers  */
+/* applied to the chosen syntax only  [ref CABACput :821-832, CABACupdate :859-879, CABACputBin(s) :899-933, putTerminate    */
+/* :882-896, CABACfinish :840-856, syntax :943-1340].  Plain serial code: with one active lane a branch costs nothing.        */
+/* It is sliced by 8x8 position: slice r (z-order) writes the CU whose origin is that position, so that it fits in the shadow */
+/* of the NxN chain of the analysis round r.                                                                                  */
+/* --------------------------------------------------------------------------------------------- */
+struct HvWr { int range; unsigned low; int nbits, pending, held, zeros, n, epb; HV_GLOBAL u8 *out; };
+static HD HvWr hv_wr_load(const HvLds &S, const HevceImageDesc &im) {
+    HvWr w = { S.wr.range, S.wr.low, S.wr.nbits, S.wr.nbytes, S.wr.bufbyte, S.wr.zeros, S.wr.nout, S.wr_epb, (HV_GLOBAL u8 *)im.payload };
+    return w;
 }
-static HD HvEmit hv_em_load(const HvLds &S, const HevceImageDesc &im) { HvEmit e = { S.em_held, S.em_pending, S.em_zeros, S.em_n, (HV_GLOBAL u8 *)im.payload }; return e; }
-static HD void hv_em_store(HvLds &S, const HvEmit &e) { S.em_held = e.held; S.em_pending = e.pending; S.em_zeros = e.zeros; S.em_n = e.n; }
-/* records [S.em_rd, S.em_rd + limit) of log `which`, fetched eight at a time one chunk ahead.  One lane (wavefront 4, lane 0). */
-static HD void hv_emit_ctu(HvLds &S, const HevceImageDesc &im, int which, int limit) {
-    const HV_GLOBAL HvChunk *log8 = (const HV_GLOBAL HvChunk *)((const HV_GLOBAL u16 *)im.leadlog + which * HEVCE_LEADLOG_WORDS);
-    const int n = S.em_cnt[which], pos = S.em_rd, end = hv_min(n, pos + hv_min(limit, HEVCE_LEADLOG_WORDS));
-    if (pos >= end) return;
-    HvEmit e = hv_em_load(S, im);
-    HvChunk nxt = log8[(pos >> 3) & (HEVCE_LEADLOG_WORDS / 8 - 1)];
-    for (int base = pos & ~7; base < end; base += 8) {
-        const HvChunk cur = nxt;
-        nxt = log8[((base >> 3) + 1) & (HEVCE_LEADLOG_WORDS / 8 - 1)];
-        for (int j = 0; j < 8; j++) {
-            if (base + j < pos || base + j >= end) continue;
-            const int lead = (int)((cur[j >> 1] >> ((j & 1) << 4)) & 0xffffu);
-            if (lead == 0xff) { e.pending++; continue; }
-            if (e.pending > 0) {
-                const int c = lead >> 8, fill = (0xff + c) & 0xff;
-                hv_em_put(e, e.held + c);
-                e.held = lead & 0xff;
-                for (; e.pending > 1; e.pending--) hv_em_put(e, fill);
-            } else { e.pending = 1; e.held = lead; }             /* first byte ever: stored unmasked, as the reference does */
+static HD void hv_wr_store(HvLds &S, const HvWr &w) {
+    S.wr.range = w.range; S.wr.low = w.low; S.wr.nbits = w.nbits; S.wr.nbytes = w.pending; S.wr.bufbyte = w.held; S.wr.zeros = w.zeros; S.wr.nout = w.n; S.wr.pad = 0;
+    S.wr_epb = w.epb;
+}
+static HD void hv_wr_put(HvWr &w, int byte) {                                                              /* [ref :821-832] */
+    byte &= 0xff;
+    if (w.zeros >= 2 && byte <= 3) { if (w.out) w.out[w.n] = 3; w.n++; w.zeros = 0; w.epb++; }
+    if (w.out) w.out[w.n] = (u8)byte;
+    w.n++;
+    w.zeros = byte ? 0 : w.zeros + 1;
+}
+static HD void hv_wr_carry(HvWr &w) {                                                                      /* [ref :859-879] */
+    if (w.nbits >= 12) return;
+    const int lead = (int)(w.low >> (24 - w.nbits));
+    w.nbits += 8;
+    w.low &= 0xffffffffu >> w.nbits;
+    if (lead == 0xff) { w.pending++; return; }
+    if (w.pending > 0) {
+        const int c = lead >> 8, fill = (0xff + c) & 0xff;
+        hv_wr_put(w, w.held + c);
+        w.held = lead & 0xff;
+        for (; w.pending > 1; w.pending--) hv_wr_put(w, fill);
+    } else { w.pending = 1; w.held = lead; }                     /* first byte ever: stored unmasked, as the reference does */
+}
+static HD void hv_wr_bin(HvLds &S, HvWr &w, int ci, int bin) {                                              /* [ref :914-933] */
+    const int v = S.wr_ctx[ci], st = v >> 1, mps = v & 1;
+    const int lps = (int)((S.lps4[st] >> (((w.range >> 6) & 3) << 3)) & 0xff);
+    w.range -= lps;
+    if ((bin != 0) != (mps != 0)) {
+        const int sh = (lps < 8) ? 6 : hv_clz((unsigned)(lps >> 3)) - 26;
+        S.wr_ctx[ci] = (u8)(st == 0 ? (mps ^ 1) : ((S.lpsnext[st] << 1) | mps));
+        w.low = (w.low + (unsigned)w.range) << sh;
+        w.range = lps << sh;
+        w.nbits -= sh;
+    } else {
+        if (st < 62) S.wr_ctx[ci] = (u8)(v + 2);
+        if (w.range < 256) { w.low <<= 1; w.range <<= 1; w.nbits--; }
+    }
+    hv_wr_carry(w);
+}
+static HD void hv_wr_bypass(HvWr &w, int bins, int len) {                                                  /* [ref :899-911] */
+    bins &= (1 << len) - 1;
+    while (len > 0) {
+        const int n = hv_min(len, 8);
+        len -= n;
+        w.low = (w.low << n) + (unsigned)w.range * (unsigned)((bins >> len) & ((1 << n) - 1));
+        w.nbits -= n;
+        hv_wr_carry(w);
+    }
+}
+static HD void hv_wr_terminate(HvWr &w, int bin) {                                                         /* [ref :882-896] */
+    w.range -= 2;
+    if (bin) { w.low = (w.low + (unsigned)w.range) << 7; w.range = 256; w.nbits -= 7; }
+    else if (w.range < 256) { w.low <<= 1; w.range <<= 1; w.nbits--; }
+    hv_wr_carry(w);
+}
+static HD void hv_wr_finish(HvWr &w) {                                                                     /* [ref :840-856] */
+    int fill = 0;
+    if ((w.low >> (32 - w.nbits)) > 0) { hv_wr_put(w, w.held + 1); w.low -= 1u << (32 - w.nbits); }
+    else { if (w.pending > 0) hv_wr_put(w, w.held); fill = 0xff; }
+    for (; w.pending > 1; w.pending--) hv_wr_put(w, fill);
+    const int tail = (int)((w.low >> 8) << w.nbits);
+    hv_wr_put(w, tail >> 16); hv_wr_put(w, tail >> 8); hv_wr_put(w, tail);
+}
+/* coeff_abs_level_remaining  [ref :1154-1169] */
+static HD void hv_wr_remainder(HvWr &w, int v, int k) {
+    if (v < (3 << k)) {
+        const int pre = v >> k;
+        hv_wr_bypass(w, (1 << (pre + 1)) - 2, pre + 1);
+        hv_wr_bypass(w, v & ((1 << k) - 1), k);
+    } else {
+        int len = k;
+        v -= 3 << k;
+        for (; v >= (1 << len); len++) v -= 1 << len;
+        hv_wr_bypass(w, (1 << (4 + len - k)) - 2, 4 + len - k);
+        hv_wr_bypass(w, v, len);
+    }
+}
+/* residual_coding of the n x n block at CTU-relative (y0, x0)  [ref putCoef :1173-1269]; the block is known to have a level */
+static HD void hv_wr_residual(HvLds &S, HvWr &w, int y0, int x0, int n, int lg, int mode) {
+    const int kind = hv_scan_kind(n, mode), ncg = n >> 2, ncgt = ncg * ncg;
+    const HV_LDSP short *lev = (const HV_LDSP short *)&S.wr_rec.lev[0][0];
+    /* which 4x4 groups hold a level (bit gy * 8 + gx), the last group in scan order that does, the last position inside it */
+    u64 cgsig = 0;
+    int cg_last = 0;
+    for (int cg = 0; cg < ncgt; cg++) {
+        int gy, gx;
+        hv_scan_cg(S, lg, kind, cg, gy, gx);
+        const HV_LDSP HvPair *row = (const HV_LDSP HvPair *)(lev + (y0 + gy * 4) * 32 + x0 + gx * 4);
+        const HvPair a = row[0], b = row[8], c = row[16], d = row[24];      /* four rows of four 16-bit levels, 64 bytes apart */
+        if ((a[0] | a[1] | b[0] | b[1] | c[0] | c[1] | d[0] | d[1]) != 0) { cgsig |= (u64)1 << (gy * 8 + gx); cg_last = cg; }
+    }
+    int c1 = 1, last = 0;
+    for (int cg = cg_last; cg >= 0; cg--) {
+        int gy, gx;
+        hv_scan_cg(S, lg, kind, cg, gy, gx);
+        const int first_cg = cg == 0, at_last = cg == cg_last;
+        const int cgs = (int)((cgsig >> (gy * 8 + gx)) & 1);
+        const int right = (gx < ncg - 1) ? (int)((cgsig >> (gy * 8 + gx + 1)) & 1) : 0;
+        const int below = (gy < ncg - 1) ? (int)((cgsig >> (gy * 8 + 8 + gx)) & 1) : 0;
+        const int nb = (below << 1) | right;
+        if (!cgs && !first_cg) { hv_wr_bin(S, w, CX_SIGCG + (nb != 0), 0); continue; }     /* never the last group: that one holds a level */
+        int v[16];
+        unsigned nzm = 0;
+#pragma unroll
+        for (int ii = 0; ii < 16; ii++) {
+            int iy, ix;
+            hv_scan_in(S, kind, ii, iy, ix);
+            v[ii] = lev[(y0 + gy * 4 + iy) * 32 + x0 + gx * 4 + ix];
+            nzm |= (unsigned)(v[ii] != 0) << ii;
+        }
+        int start = 15;
+        if (at_last) {
+            start = 31 - hv_clz(nzm);
+            last = (cg << 4) | start;
+            /* last_sig_coeff_x/y prefix and suffix  [ref :1046-1087]; for the vertical scan the coordinates swap */
+            int iy, ix;
+            hv_scan_in(S, kind, start, iy, ix);
+            const int y = gy * 4 + iy, x = gx * 4 + ix;
+            const int cls = lg - 2, sh = (n == 4) ? 0 : 1;
+            int ty = kind == 2 ? x : y, tx = kind == 2 ? y : x;
+            const int ggy = hv_last_group(ty), ggx = hv_last_group(tx), gmax = 2 * lg - 1;
+            for (int i = 0; i < ggx; i++) hv_wr_bin(S, w, CX_LASTX + 5 * cls + (i >> sh), 1);
+            if (ggx < gmax) hv_wr_bin(S, w, CX_LASTX + 5 * cls + (ggx >> sh), 0);
+            for (int i = 0; i < ggy; i++) hv_wr_bin(S, w, CX_LASTY + 5 * cls + (i >> sh), 1);
+            if (ggy < gmax) hv_wr_bin(S, w, CX_LASTY + 5 * cls + (ggy >> sh), 0);
+            if (ggx > 3) { tx -= hv_last_min(ggx); for (int i = ((ggx - 2) >> 1) - 1; i >= 0; i--) hv_wr_bypass(w, (tx >> i) & 1, 1); }
+            if (ggy > 3) { ty -= hv_last_min(ggy); for (int i = ((ggy - 2) >> 1) - 1; i >= 0; i--) hv_wr_bypass(w, (ty >> i) & 1, 1); }
+        } else if (!first_cg) hv_wr_bin(S, w, CX_SIGCG + (nb != 0), 1);
+        /* significance flags, highest scan position first; the last position itself is known, position 0 of a later group is
+           inferred when nothing else in the group is set  [ref :1194-1216] */
+        const u8 *tab = S.sigtab[hv_sigtab_index(n, kind, nb, first_cg)];
+        const int any_above0 = (nzm >> 1) != 0;
+#pragma unroll
+        for (int ii = 15; ii >= 0; ii--)
+            if (ii <= start && !(at_last && ii == start) && (ii != 0 || first_cg || any_above0))
+                hv_wr_bin(S, w, CX_SIG + tab[ii], (int)((nzm >> ii) & 1));
+        if (!nzm) continue;
+        /* greater1 flags of the first eight levels, one greater2 flag, signs, remainders  [ref :1218-1266] */
+        const int nz = __builtin_popcount(nzm);
+        const int set = (first_cg ? 0 : 2) + (c1 == 0);
+        int esc = nz > 8, g2 = -1, j = 0, signs = 0;
+        c1 = 1;
+#pragma unroll
+        for (int ii = 15; ii >= 0; ii--)
+            if ((nzm >> ii) & 1) {
+                const int a = hv_abs(v[ii]);
+                if (j < 8) {
+                    hv_wr_bin(S, w, CX_ONE + 4 * set + c1, a > 1);
+                    if (a > 1) { c1 = 0; if (g2 < 0) g2 = a > 2; else esc = 1; }
+                    else if (c1 > 0 && c1 < 3) c1++;
+                }
+                signs = (signs << 1) | (v[ii] < 0);
+                j++;
+            }
+        if (c1 == 0 && g2 >= 0) { hv_wr_bin(S, w, CX_ABS + set, g2); esc |= g2; }
+        hv_wr_bypass(w, signs, nz);
+        if (esc) {
+            int base = 3, rice = 0;
+            j = 0;
+#pragma unroll
+            for (int ii = 15; ii >= 0; ii--)
+                if ((nzm >> ii) & 1) {
+                    const int a = hv_abs(v[ii]), rem = a - (j < 8 ? base : 1);
+                    if (rem >= 0) {
+                        hv_wr_remainder(w, rem, rice);
+                        if (a > (3 << rice)) rice = hv_min(rice + 1, 4);
+                    }
+                    if (a >= 2) base = 2;
+                    j++;
+                }
         }
     }
-    hv_em_store(S, e);
-    S.em_rd = end;
+    (void)last;
 }
-static HD void hv_emit_finish(HvLds &S, const HevceImageDesc &im) {
-    HvEmit e = hv_em_load(S, im);
-    unsigned low = S.com.low;
-    const int bits = S.com.nbits;
-    int fill = 0;
-    if ((low >> (32 - bits)) > 0) { hv_em_put(e, e.held + 1); low -= 1u << (32 - bits); }
-    else { if (e.pending > 0) hv_em_put(e, e.held); fill = 0xff; }
-    for (; e.pending > 1; e.pending--) hv_em_put(e, fill);
-    const int tail = (int)((low >> 8) << bits);
-    hv_em_put(e, tail >> 16); hv_em_put(e, tail >> 8); hv_em_put(e, tail);
-    hv_em_store(S, e);
-    *im.payload_len = e.n;
+static HD int hv_wr_nonzero(const HvLds &S, int y0, int x0, int n) {
+    const HV_LDSP short *lev = (const HV_LDSP short *)&S.wr_rec.lev[0][0];
+    unsigned any = 0;
+    for (int i = 0; i < n; i++)
+        for (int jx = 0; jx < n; jx += 4) {
+            const HvPair a = *(const HV_LDSP HvPair *)(lev + (y0 + i) * 32 + x0 + jx);
+            any |= a[0] | a[1];
+        }
+    return any != 0;
+}
+/* neighbour context of the CTU being written, with the reference's line-buffer semantics  [ref :1369-1373, 1595-1600, 1634-1637]:
+   CU size 32 outside the picture; mode DC outside the picture and across a CTU-row boundary */
+static HD int hv_wr_cu_left(const HvLds &S, int L, int y, int x)  { return x > 0 ? 8 << (S.wr_rec.info[y >> 2][(x >> 2) - 1] & HEVCE_INFO_LOG2_MASK) : (L ? 8 << (S.wr_linfo[y >> 2] & HEVCE_INFO_LOG2_MASK) : 32); }
+static HD int hv_wr_cu_above(const HvLds &S, int A, int y, int x) { return y > 0 ? 8 << (S.wr_rec.info[(y >> 2) - 1][x >> 2] & HEVCE_INFO_LOG2_MASK) : (A ? 8 << (S.wr_ainfo[x >> 2] & HEVCE_INFO_LOG2_MASK) : 32); }
+static HD int hv_wr_pm_left(const HvLds &S, int L, int y, int x)  { return x > 0 ? S.wr_rec.mode[y >> 2][(x >> 2) - 1] : (L ? S.wr_lmode[y >> 2] : 1); }
+static HD int hv_wr_pm_above(const HvLds &S, int y, int x)        { return y > 0 ? S.wr_rec.mode[(y >> 2) - 1][x >> 2] : 1; }
+/* one coding unit of size n at CTU-relative (y, x)  [ref putCU_* :1272-1340] */
+static HD void hv_wr_cu(HvLds &S, HvWr &w, int L, int y, int x, int n, int info) {
+    const int i4 = y >> 2, j4 = x >> 2;
+    const int nxn = (info & HEVCE_INFO_NXN) != 0, split = (info & HEVCE_INFO_TUSPLIT) != 0;
+    const int lg = n == 8 ? 3 : n == 16 ? 4 : 5;
+    int modes[4], left[4], above[4];
+    modes[0] = S.wr_rec.mode[i4][j4]; left[0] = hv_wr_pm_left(S, L, y, x); above[0] = hv_wr_pm_above(S, y, x);
+    if (nxn) {
+        for (int s = 1; s < 4; s++) modes[s] = S.wr_rec.mode[i4 + (s >> 1)][j4 + (s & 1)];
+        left[1] = modes[0];                       above[1] = hv_wr_pm_above(S, y, x + 4);
+        left[2] = hv_wr_pm_left(S, L, y + 4, x);  above[2] = modes[0];
+        left[3] = modes[2];                       above[3] = modes[1];
+    }
+    if (n == 8) hv_wr_bin(S, w, CX_PART, !nxn);
+    const int parts = nxn ? 4 : 1;
+    int hit[4], rem[4];
+    for (int i = 0; i < parts; i++) {                            /* [ref :958-1018] */
+        int p[3];
+        hv_mpm(left[i], above[i], p);
+        const int md = modes[i];
+        hit[i] = (p[2] == md) ? 2 : (p[1] == md) ? 1 : (p[0] == md) ? 0 : -1;
+        const int hi = hv_max(p[0], hv_max(p[1], p[2])), lo = hv_min(p[0], hv_min(p[1], p[2])), mid = p[0] + p[1] + p[2] - hi - lo;
+        int r = md;
+        r -= (r > hi); r -= (r > mid); r -= (r > lo);
+        rem[i] = r;
+        hv_wr_bin(S, w, CX_YPM, hit[i] >= 0);
+    }
+    for (int i = 0; i < parts; i++) {
+        if (hit[i] >= 0) { hv_wr_bypass(w, hit[i] > 0, 1); if (hit[i] > 0) hv_wr_bypass(w, hit[i] - 1, 1); }
+        else hv_wr_bypass(w, rem[i], 5);
+    }
+    hv_wr_bin(S, w, CX_UVPM, 0);
+    if (!nxn) hv_wr_bin(S, w, CX_SPLIT_TU + (5 - lg), split);
+    hv_wr_bin(S, w, CX_UVCBF, 0);
+    hv_wr_bin(S, w, CX_UVCBF, 0);
+    if (!nxn && !split) {
+        const int cbf = hv_wr_nonzero(S, y, x, n);
+        hv_wr_bin(S, w, CX_YCBF + 1, cbf);
+        if (cbf) hv_wr_residual(S, w, y, x, n, lg, modes[0]);
+    } else {
+        const int h = n >> 1;
+        for (int s = 0; s < 4; s++) {
+            const int sy = y + (s >> 1) * h, sx = x + (s & 1) * h;
+            const int cbf = hv_wr_nonzero(S, sy, sx, h);
+            hv_wr_bin(S, w, CX_YCBF, cbf);
+            if (cbf) hv_wr_residual(S, w, sy, sx, h, lg - 1, modes[nxn ? s : 0]);
+        }
+    }
+}
+/* the writer starts on CTU `cw`: stage its record and its neighbours' CU sizes / modes in LDS.  Whole wavefront.
+   The records were stored by this workgroup (barriers since); agent-scope loads so that no stale line of a record
+   that was rewritten (a CTU analysed twice) can be picked up. */
+static HD void hv_wr_stage(HvLds &S, const HevceImageDesc &im, int cw) {
+    const int lane = hv_tid() & 63, ncx = im.W >> 5;
+    const unsigned *src = (const unsigned *)(im.records + (size_t)cw * HEVCE_REC_BYTES);
+    HV_LDSP unsigned *dst = (HV_LDSP unsigned *)&S.wr_rec;
+    for (int i = lane; i < HEVCE_REC_BYTES / 4; i += 64) dst[i] = hv_ldg_u32(src + i);
+    if (lane < 8 && (cw % ncx) > 0) {
+        const HevceRecord *l = (const HevceRecord *)(im.records + (size_t)(cw - 1) * HEVCE_REC_BYTES);
+        const unsigned wi = hv_ldg_u32((const unsigned *)&l->info[lane][4]);
+        const unsigned wm = hv_ldg_u32((const unsigned *)&l->mode[lane][4]);
+        S.wr_linfo[lane] = (u8)(wi >> 24); S.wr_lmode[lane] = (u8)(wm >> 24);
+    }
+    if (lane >= 8 && lane < 10 && cw >= ncx) {
+        const HevceRecord *a = (const HevceRecord *)(im.records + (size_t)(cw - ncx) * HEVCE_REC_BYTES);
+        const unsigned wi = hv_ldg_u32((const unsigned *)&a->info[7][(lane - 8) * 4]);
+        for (int k = 0; k < 4; k++) S.wr_ainfo[(lane - 8) * 4 + k] = (u8)(wi >> (8 * k));
+    }
+}
+/* slice r of CTU cw: the split flags and the CU that start at 8x8 position r (z-order); after the last slice the
+   end_of_slice_segment_flag, the coder registers of the CTU and -- last CTU -- the coder's tail.  One lane. */
+static HDN void hv_wr_slice(const HevceImageDesc &im, int cw, int r) {
+    HvLds &S = HV_S;
+    const int ncx = im.W >> 5, nctu = ncx * (im.H >> 5);
+    const int L = (cw % ncx) > 0, A = cw >= ncx;
+    HvWr w = hv_wr_load(S, im);
+    const int k16 = r >> 2, m = r & 3;
+    const int y16 = (k16 >> 1) * 16, x16 = (k16 & 1) * 16, y8 = y16 + (m >> 1) * 8, x8 = x16 + (m & 1) * 8;
+    const int info = S.wr_rec.info[y8 >> 2][x8 >> 2], size = 8 << (info & HEVCE_INFO_LOG2_MASK);
+    if (r == 0) {                                                                                           /* [ref :943-947, 1403-1404] */
+        const int inc = (32 > hv_wr_cu_left(S, L, 0, 0)) + (32 > hv_wr_cu_above(S, A, 0, 0));
+        hv_wr_bin(S, w, CX_SPLIT_CU + inc, size < 32);
+        if (size == 32) hv_wr_cu(S, w, L, 0, 0, 32, info);
+    }
+    if (size < 32 && m == 0) {
+        const int inc = (16 > hv_wr_cu_left(S, L, y16, x16)) + (16 > hv_wr_cu_above(S, A, y16, x16));
+        hv_wr_bin(S, w, CX_SPLIT_CU + inc, size < 16);
+        if (size == 16) hv_wr_cu(S, w, L, y16, x16, 16, info);
+    }
+    if (size == 8) hv_wr_cu(S, w, L, y8, x8, 8, info);
+    if (r == 15) {
+        hv_wr_terminate(w, cw == nctu - 1);                                                                 /* [ref :1630] */
+        if (im.ctu_state) {
+            int32_t *st = im.ctu_state + (size_t)cw * 8;
+            st[0] = w.range; st[1] = (int32_t)w.low; st[2] = w.nbits; st[3] = w.pending; st[4] = w.held; st[5] = w.zeros;
+            st[6] = w.n; st[7] = 8 * (w.n + w.pending) + 23 - w.nbits;
+        }
+        if (cw == nctu - 1) { hv_wr_finish(w); if (im.payload_len) *im.payload_len = w.n; }               /* [ref :1640-1641] */
+    }
+    hv_wr_store(S, w);
 }
 
 /* TU-job phase of the 8x8 CU number m (0..3) of the 16x16 CU number k16 (0..3).  Wavefront 0 walks the NxN chain, the
@@ -1916,7 +2174,15 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         hv_job_nxn(wave, lane, q, c8, (HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3) + (size_t)70 * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0);
         return;
     }
-    if (wv == 4) return;                                         /* shares its SIMD with wavefront 0: idle */
+    if (wv == 4) {
+        /* shares its SIMD with wavefront 0, so no jobs: one of its lanes writes the previous CTU's slice data instead (slice = this
+           round's 8x8 position); the older wavefront 0 wins the SIMD's issue arbitration */
+        if (im.payload && ctu > 0) {
+            if (k16 == 0 && m == 0) { hv_wr_stage(S, im, ctu - 1); WAVE_SYNC(); }
+            if (lane == 0) hv_wr_slice(im, ctu - 1, k16 * 4 + m);
+        }
+        return;
+    }
     const int w1 = wv < 4 ? wv - 1 : wv - 2;                     /* work slot 0..5 */
     HvGLev l0 = (HvGLev)s0, l1 = (HvGLev)s1, l2 = (HvGLev)s2;
     HvGRec r0 = (HvGRec)(s0 + HV_TL * 1024 * 2), r1 = (HvGRec)(s1 + HV_TL * 1024 * 2), r2 = (HvGRec)(s2 + HV_TL * 1024 * 2);
@@ -2011,16 +2277,6 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
     if (w < 0) return;                                          /* the four sub-CUs stay */
 
     /* ---------------- commit the winner: coder, contexts, reconstruction, maps, record ---------------- */
-    if (im.leadlog) {
-        /* its finished bytes take the place of whatever this CU had pushed so far (the split flag and the sub-CUs' bytes of a
-           16x16 / 32x32 CU that ends up unsplit) */
-        const int base = (n > 8) ? S.em_mark[cu.lvl] : S.em_pos, cnt = L.tnlog[w];
-        HV_GLOBAL u16 *log = (HV_GLOBAL u16 *)im.leadlog + (ctu & 1) * HEVCE_LEADLOG_WORDS;
-        const HV_GLOBAL u16 *src = (const HV_GLOBAL u16 *)(scr + HV_TL * 1024 * 3 + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT * 2) + (size_t)w * HEVCE_SINK_WORDS;
-        for (int i = tid; i < cnt; i += HV_NTHREADS) log[(base + i) & (HEVCE_LEADLOG_WORDS - 1)] = src[i];
-        BLOCK_SYNC();
-        if (tid == 0) S.em_pos = base + cnt;
-    }
     if (tid == 0) S.com = L.tregs[w];
     if (tid < HEVCE_NCTXP) S.com_ctx[tid] = L.tctx[tid][w];
     const int kindw = w < 35 ? 0 : (w < 70 ? 1 : 2);
@@ -2080,10 +2336,9 @@ static HD void hv_init_tables(HvLds &S, int q, int tid) {
         int st = ((((iv >> 4) * 5 - 45) * qp) >> 4) + ((iv & 15) << 3) - 16;
         st = hv_min(hv_max(st, 1), 126);
         const u8 v = (u8)(st >= 64 ? (((st - 64) << 1) | 1) : ((63 - st) << 1));
-        S.ctx_fresh[i] = v; S.com_ctx[i] = v;
+        S.ctx_fresh[i] = v; S.com_ctx[i] = v; S.wr_ctx[i] = v;
     }
-    if (tid == 301) { S.em_pos = 0; S.em_rd = 0; S.em_slice = 0; S.em_cnt[0] = S.em_cnt[1] = 0; S.em_held = 0xff; S.em_pending = 0; S.em_zeros = 0; S.em_n = 0; }
-    if (tid == 300) { S.com.range = 510; S.com.low = 0; S.com.nbits = 23; S.com.nbytes = 0; S.com.bufbyte = 0xff; S.com.zeros = 0; S.com.nout = 0; S.com.pad = 0; }
+    if (tid == 300) { S.com.range = 510; S.com.low = 0; S.com.nbits = 23; S.com.nbytes = 0; S.com.bufbyte = 0xff; S.com.zeros = 0; S.com.nout = 0; S.com.pad = 0; S.wr = S.com; S.wr_epb = 0; }
 }
 
 /* second init step (after the scan tables exist): significance-context tables  [ref :1092-1122 evaluated per position] */
@@ -2108,8 +2363,10 @@ static HD void hv_snapshot(HvLds &S, int lvl, int tid) {
 static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int tid = hv_tid(), q = im.qpd6, H = im.H, W = im.W;
     if (tid == 0) S.trace = im.trace;
+#ifdef HEVCE_ANYPROF
     if (tid < 24) (&S.prof[0][0])[tid] = 0;
     if (tid < 32) S.prof2[tid] = 0;
+#endif
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     const unsigned long long prof_start_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -2168,14 +2425,14 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     hv_snapshot(S, 2, tid);
                     hv_level_begin(S, c32);
                     BLOCK_SYNC();
-                    if (tid == 0) { S.em_mark[2] = S.em_pos; hv_commit_bin(S, im, ctu, CX_SPLIT_CU + S.lv[2].split_inc, 1); }
+                    if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + S.lv[2].split_inc, 1);
                     BLOCK_SYNC();
                 }
                 if (step < 20 && m == 0) {                       /* entering a 16x16 CU */
                     hv_snapshot(S, 1, tid);
                     hv_level_begin(S, c16);
                     BLOCK_SYNC();
-                    if (tid == 0) { S.em_mark[1] = S.em_pos; hv_commit_bin(S, im, ctu, CX_SPLIT_CU + S.lv[1].split_inc, 1); }
+                    if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + S.lv[1].split_inc, 1);
                     BLOCK_SYNC();
                 }
                 if (cu.n == 8) {
@@ -2209,12 +2466,9 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
             if (tid == 0) {
                 HvCod c;
                 hv_cod_load(c, S.com);
-                hv_terminate(c, (y0 + 32 >= H) && (x0 + 32 >= W), im.leadlog ? (HV_GLOBAL u16 *)im.leadlog + (ctu & 1) * HEVCE_LEADLOG_WORDS : nullptr, &S.em_pos);
+                hv_terminate(c, (y0 + 32 >= H) && (x0 + 32 >= W));
                 hv_cod_store(S.com, c);
-                if (im.payload && ctu > 0) hv_emit_ctu(S, im, (ctu - 1) & 1, HEVCE_LEADLOG_WORDS);   /* what the slices left of the previous CTU's (normally nothing) */
-                S.em_cnt[ctu & 1] = S.em_pos; S.em_pos = 0;      /* this CTU's bytes are complete: wavefront 4 emits them during the next CTU, */
-                S.em_rd = 0; S.em_slice = (S.em_cnt[ctu & 1] + 13) / 14;   /* in fourteen of its sixteen engine phases */
-                if (im.ctu_state) {
+                if (im.ctu_state && !im.payload) {               /* without the stream writer: the analysis' own coder registers */
                     int32_t *st = im.ctu_state + (size_t)ctu * 8;
                     st[0] = c.range; st[1] = (int32_t)c.low; st[2] = c.nbits; st[3] = c.nbytes; st[4] = c.bufbyte; st[5] = c.zeros;
                     st[6] = c.nout; st[7] = hv_cod_bits(c);
@@ -2227,7 +2481,12 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
             BLOCK_SYNC();
         }
     }
-    if (im.payload && tid == 0) { hv_emit_ctu(S, im, (ctu - 1) & 1, HEVCE_LEADLOG_WORDS); hv_emit_finish(S, im); }   /* the last CTU's bytes and the coder's tail */
+    /* the last CTU's slice data and the coder's tail: nothing left to overlap it with */
+    if (im.payload && (tid >> 6) == 4) {
+        hv_wr_stage(S, im, ctu - 1);
+        WAVE_SYNC();
+        if (tid == 4 * 64) for (int r = 0; r < 16; r++) hv_wr_slice(im, ctu - 1, r);
+    }
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     if (im.trace && tid < 24) { ((unsigned long long *)im.trace)[tid] = (&S.prof[0][0])[tid]; }
     if (im.trace && tid < 32) { ((unsigned long long *)im.trace)[24 + tid] = S.prof2[tid]; }
