@@ -61,6 +61,8 @@ def lib():
         L.HEVCImageEncoderTiles.restype = C.c_int
         L.HEVCImageEncoderTiles.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_u8p), _i32p, C.POINTER(_u8p)]
         L.hevce_job_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.hevce_job_set_flags.argtypes = [C.c_void_p, C.c_int]
+        L.hevce_job_stats.argtypes = [C.c_void_p, C.c_int, _i32p]
         for f in ("hevce_job_run", "hevce_job_launch", "hevce_job_finish"):
             getattr(L, f).argtypes = [C.c_void_p]
         L.hevce_job_stream.restype = _u8p
@@ -190,6 +192,16 @@ class Job:
 
     def run(self):
         _check(lib().hevce_job_run(self._h), "hevce_job_run")
+
+    def set_flags(self, flags):
+        """tests: bit 0 exact coders throughout; bits 8-15 / 16-23 forced re-analysis periods (include/hevce_mi355x.h)"""
+        _check(lib().hevce_job_set_flags(self._h, int(flags)), "hevce_job_set_flags")
+
+    def stats(self, i=0):
+        """(CTUs analysed twice, coder consistency failures) of image i in the last run"""
+        out = (C.c_int * 2)()
+        _check(lib().hevce_job_stats(self._h, int(i), out), "hevce_job_stats")
+        return int(out[0]), int(out[1])
 
     def launch(self):
         _check(lib().hevce_job_launch(self._h), "hevce_job_launch")

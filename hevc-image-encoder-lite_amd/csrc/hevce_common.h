@@ -62,12 +62,14 @@ typedef struct HevceImageDesc {
     int64_t src_stride;
     int32_t       *dump;      /* diagnostics: per CU evaluation, 72 x (sse, cost) ints (NULL = off) */
     int32_t       *trace;     /* diagnostics: host-pinned, 16 ints per wavefront (only written by HEVCE_TRACE builds) */
-    /* device-side byte emission; all three NULL = off, the host writer replays the records instead */
+    /* the kernel's stream writer: the slice data bytes.  payload == NULL: no writer; the analysis then runs
+       with the EXACT engines throughout and the host replays the records (hevce_write_stream) */
     uint8_t       *payload;   /* out: the slice data bytes (what follows the VPS/SPS/PPS/slice header) */
-    uint16_t      *leadlog;   /* 2 x HEVCE_LEADLOG_WORDS: the finished bytes (9-bit: carry + byte) of the CTU in flight / the one before */
     int32_t       *payload_len;
+    int32_t       *stats;     /* optional, 2 ints: CTUs analysed twice (EXACT after FAST), consistency failures (must be 0) */
+    int32_t        flags;     /* tests: bit 0 EXACT engines throughout; bits 8-15 / 16-23: forced re-analysis periods (hevce_device.h) */
+    int32_t        pad_;
 } HevceImageDesc;
-#define HEVCE_LEADLOG_WORDS 4096                             /* per CTU; the reference itself cannot exceed 3200 bytes per CTU (HEVCe.c:795) */
 
 #define HEVCE_TRIALS        72                               /* 35 + 35 + 1 (+1 pad) trial slots */
 #define HEVCE_TOKEN_SLOT_WORDS 128                           /* 16-bit words per bin-token slot */

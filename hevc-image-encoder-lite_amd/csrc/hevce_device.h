@@ -22,6 +22,13 @@
 #define HV_LDSP
 #define HV_KEEP(x) do { } while (0)
 static inline unsigned hv_ldg_u32(const unsigned *p) { return *p; }
+static inline unsigned hv_perm(unsigned a, unsigned b, unsigned sel) {
+    const unsigned long long src = ((unsigned long long)a << 32) | b;
+    unsigned r = 0;
+    for (int i = 0; i < 4; i++) { const unsigned k = (sel >> (8 * i)) & 0xff; r |= (k < 8 ? (unsigned)((src >> (8 * k)) & 0xff) : (k >= 0x0d ? 0xffu : 0u)) << (8 * i); }
+    return r;
+}
+static inline void hv_atomic_add(int *p, int v) { *p += v; }
 #else
 #include <hip/hip_runtime.h>
 #define HD  __device__ __forceinline__
@@ -62,6 +69,8 @@ static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v
 static HD int  hv_clz_nz(unsigned v) { return __builtin_clz(v); }   /* v != 0: the bare instruction */
 static HD unsigned long long hv_ballot(int p) { return __ballot(p); }   /* one bit per active lane */
 static HD int  hv_clzll(unsigned long long v) { return __clzll((long long)v); }
+static HD unsigned hv_perm(unsigned a, unsigned b, unsigned sel) { return __builtin_amdgcn_perm(a, b, sel); }   /* v_perm_b32: result byte i = byte sel.byte[i] of {a:7..4, b:3..0} */
+static HD void hv_atomic_add(int *p, int v) { atomicAdd(p, v); }
 static HD unsigned hv_ldg_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   /* read at the L2: never a stale L1 line */
 #endif
 
@@ -162,7 +171,10 @@ struct alignas(16) HvLds {
     /* tables (copied from constant memory so that per-lane divergent lookups are LDS reads) */
     unsigned lps4[64];
     u8  lpsnext[64];
-    alignas(8) unsigned ctab[128][2];                       /* [context byte]: { four LPS ranges (one byte per range quarter), next byte after LPS | after MPS << 8 } */
+    union {                                                 /* rebuilt when the workgroup changes mode (hv_set_mode) */
+        alignas(8) unsigned ctab[128][2];                   /* EXACT: [context byte]: { four LPS ranges (one byte per range quarter), next byte after LPS | after MPS << 8 } */
+        alignas(8) unsigned ctab2[256][2];                  /* FAST: [context byte << 1 | bin]: { four LPS ranges, next context byte | is-LPS << 8 } */
+    };
     u8  sigtab[35][16];                                     /* sig_coeff_flag context per scan position of a 4x4 group, by (size class, scan, neighbours, first group) */                         /* context byte after an MPS / LPS  [ref HEVCe.c:701-702] */
     u8  d4pos[16], d4idx[16];                               /* diagonal scan inside a 4x4 group: idx->(y<<2|x), (y<<2|x)->idx */
     short ang[36], invang[36];                              /* intra angle / inverse angle per mode: a per-lane read of a __constant__ table is a waterfall of scalar loads */
@@ -200,11 +212,23 @@ struct alignas(16) HvLds {
     u8    nxn_line[35][16];                                 /* per mode: angular reference line r(-4..9) */
     u8    nxn_bord[20];                                     /* raw reference samples of the current 4x4: corner, left[8], above[8] */
     int   nxn_modes[4];
-    alignas(16) u16 nxn_sink[35][96];                       /* finished-byte records of the chain's engines (a 4x4 block: < 80 bytes) */
-    int   nxn_ntok[35];                                     /* tokens per mode of the current 4x4 block */
-    int   c70_len;                                          /* tokens of candidate 70's stream so far */
+    union {
+        alignas(16) u16 nxn_sink[35][96];                   /* EXACT: finished-byte records of the chain's engines (a 4x4 block: < 80 bytes) */
+        struct {                                            /* FAST: the winners of the CTU's 64 sub-searches, for hv_verify_nxn */
+            alignas(16) short nxv_lev[64][16];              /* levels in scan order */
+            u16   nxv_info[64];                             /* last position | scan kind << 4 | has levels << 6 */
+            short nxv_bits[64];                             /* the bit count the FAST engine gave it */
+        };
+    };
+    int   nxn_ntok[35];                                     /* per mode of the current 4x4 block: tokens | bypass bins << 8 | bits << 20 */
+    int   c70_len, c70_byp;                                 /* tokens / bypass bins of candidate 70's stream so far */
     u8    nxn_ctx[HEVCE_NCTXP][HV_TL];                      /* context columns of the NxN chain's 35 modes (fresh per 4x4 block) */
     /* control */
+    int exact;                                              /* 1: EXACT engines (the reference's bit counts by construction); 0: FAST (see hv_fengine_chunk) */
+    int poison;                                             /* FAST: this CTU's decisions may differ from the reference's: 1 = NxN winner, 2 = the writer says so */
+    int wr_done;                                            /* CTUs the writer has finished */
+    struct Snap { HevceCoderRegs com; u8 com_ctx[HEVCE_NCTXP]; u8 map_cu8[8], map_pm8[8], rec_col[32], line_cu[8]; } snap[2];   /* what a CTU starts from, [ctu & 1] */
+    HevceCoderRegs wsnap; u8 wsnap_ctx[HEVCE_NCTXP];        /* what the writer started its current CTU from */
     int winner, split_sse;
     int l0_active;                                          /* 8x8 candidates whose engines still run in this engine phase */
     int nxn_busy;                                           /* 1 while wavefront 0 walks the NxN chain of the current 8x8 CU */
@@ -432,9 +456,15 @@ static HD void hv_terminate(HvCod &c, int bin) {              /* [ref :882-896] 
 #define HV_SLOTS_TRIAL HEVCE_TOKEN_SLOTS                     /* CU header + at most 4 x (1 + 16) or 1 + 64 block/group slots            */
 #define HV_TOK_BYP     0x8000
 #define HV_TOK_NOP     HV_TOK_BYP
+/* FAST streams (range-only engines, see hv_fengine_chunk) hold context-coded bins only; the bypass bins are COUNTED at
+   binarisation (they do not move the range), and a bin on the pad context -- context byte HV_PADCV, whose table entry has an
+   LPS range of 0 and is its own successor -- is the no-op that pads a slot to whole chunks */
+#define HV_CT_PAD      (HEVCE_NCTXP - 1)
+#define HV_PADCV       126
+#define HV_TOK_NOPF    (HV_CT_PAD * HV_TL)
 #define HV_CT(idx, bin) (((idx) * HV_TL) | ((bin) ? 0x4000 : 0))   /* context-coded bin */
 
-template <typename P> struct HvTokW { P p; int n; };
+template <typename P, bool FAST = false> struct HvTokW { P p; int n; int byp; enum { fast = FAST }; };
 #define HV_SLOT_TOK0 8                      /* tokens start 16 bytes into the slot so that chunks of 8 load as one dwordx4 */
 
 static HD void hv_mpm(int left, int above, int out[3]) {                                                   /* [ref :958-977] */
@@ -451,9 +481,14 @@ struct HvModes { int mode[4], left[4], above[4]; };
 /* Token writers.  hv_emit() is branch-free: the token is always stored at the write position and the position advances
    only when `on`; a slot has headroom for the extra store (<= 110 of 120 token words are ever counted).
    HvTokW<P>: direct stores (slots in LDS: the NxN sub-search). */
-template <typename P> static HD void hv_emit(HvTokW<P> &w, int tok, int on) { w.p[HV_SLOT_TOK0 + w.n] = (u16)tok; w.n += on; }
-template <typename P> static HD void hv_tok_checkpoint(HvTokW<P> &) { }
-template <typename P> static HD int  hv_tok_finish(HvTokW<P> &w) { return w.n; }                /* tokens */
+template <typename P, bool F> static HD void hv_emit(HvTokW<P, F> &w, int tok, int on) { w.p[HV_SLOT_TOK0 + w.n] = (u16)tok; w.n += on; }
+template <typename P, bool F> static HD void hv_tok_checkpoint(HvTokW<P, F> &) { }
+template <typename P, bool F> static HD int  hv_tok_finish(HvTokW<P, F> &w) { return w.n; }                /* tokens */
+/* one chunk of <= 8 bypass bins: a token, or -- FAST -- only its length */
+template <typename WR> static HD void hv_emit_b(WR &w, int bins, int len, int on) {
+    if constexpr (WR::fast) w.byp += on ? len : 0;
+    else hv_emit(w, HV_TOK_BYP | (len << 8) | bins, on);
+}
 
 /* Writer for slots in HBM.  Sixty-four lanes storing single 16-bit tokens into sixty-four different slots cost one
    memory transaction per lane and token (measured: 60 % of the binarisation time).  Tokens therefore go to a small ring
@@ -461,31 +496,31 @@ template <typename P> static HD int  hv_tok_finish(HvTokW<P> &w) { return w.n; }
    and leave it as 16-byte chunks.  hv_tok_checkpoint() writes out up to three complete chunks; between two checkpoints
    at most 24 tokens may be added. */
 typedef unsigned __attribute__((may_alias)) HvRingWord;    /* written as 16-bit halves, read back as dwords */
-struct HvTokRing { HV_LDSP HvRingWord *ring; HV_GLOBAL u16 *slot; int n, fl; };
-static HD HvTokRing hv_tok_ring(HvLds &S, HV_GLOBAL u16 *slot) {
+template <bool FAST> struct HvTokRingT { HV_LDSP HvRingWord *ring; HV_GLOBAL u16 *slot; int n, fl, byp; enum { fast = FAST }; };
+template <bool FAST> static HD HvTokRingT<FAST> hv_tok_ring(HvLds &S, HV_GLOBAL u16 *slot) {
     const int tid = hv_tid();
-    HvTokRing w = { (HV_LDSP HvRingWord *)&S.ws[tid >> 6] + (tid & 63), slot, 0, 0 };
+    HvTokRingT<FAST> w = { (HV_LDSP HvRingWord *)&S.ws[tid >> 6] + (tid & 63), slot, 0, 0, 0 };
     return w;
 }
-static HD void hv_emit(HvTokRing &w, int tok, int on) {
+template <bool F> static HD void hv_emit(HvTokRingT<F> &w, int tok, int on) {
     ((HV_LDSP u16 *)(w.ring + ((w.n >> 1) & 15) * 64))[w.n & 1] = (u16)tok;
     w.n += on;
 }
-static HD void hv_tok_flush_chunk(HvTokRing &w) {
+template <bool F> static HD void hv_tok_flush_chunk(HvTokRingT<F> &w) {
     const HV_LDSP HvRingWord *r = w.ring + ((w.fl >> 1) & 15) * 64;
     HvChunk c;
     c[0] = r[0]; c[1] = r[64]; c[2] = r[128]; c[3] = r[192];
     *(HV_GLOBAL HvChunk *)(w.slot + HV_SLOT_TOK0 + w.fl) = c;
     w.fl += 8;
 }
-static HD void hv_tok_checkpoint(HvTokRing &w) {
+template <bool F> static HD void hv_tok_checkpoint(HvTokRingT<F> &w) {
     if (w.n - w.fl >= 8) hv_tok_flush_chunk(w);
     if (w.n - w.fl >= 8) hv_tok_flush_chunk(w);
     if (w.n - w.fl >= 8) hv_tok_flush_chunk(w);
 }
-static HD int hv_tok_finish(HvTokRing &w) {                   /* after a checkpoint: fewer than 8 tokens are pending */
+template <bool F> static HD int hv_tok_finish(HvTokRingT<F> &w) {                   /* after a checkpoint: fewer than 8 tokens are pending */
 #pragma unroll
-    for (int i = 0; i < 7; i++) ((HV_LDSP u16 *)(w.ring + (((w.n + i) >> 1) & 15) * 64))[(w.n + i) & 1] = (u16)HV_TOK_NOP;
+    for (int i = 0; i < 7; i++) ((HV_LDSP u16 *)(w.ring + (((w.n + i) >> 1) & 15) * 64))[(w.n + i) & 1] = (u16)(F ? HV_TOK_NOPF : HV_TOK_NOP);
     hv_tok_flush_chunk(w);                                    /* the last chunk, padded with no-ops */
     return (w.n + 7) >> 3;                                    /* chunks */
 }
@@ -513,9 +548,9 @@ template <typename WR> static HD int hv_tokenize_cu(WR &w, int n, int lg, int ki
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int on = i < parts, ishit = hit[i] >= 0;
-        hv_emit(w, HV_TOK_BYP | (1 << 8) | (hit[i] > 0), on && ishit);
-        hv_emit(w, HV_TOK_BYP | (1 << 8) | ((hit[i] - 1) & 1), on && hit[i] > 0);
-        hv_emit(w, HV_TOK_BYP | (5 << 8) | (rem[i] & 31), on && !ishit);
+        hv_emit_b(w, hit[i] > 0, 1, on && ishit);
+        hv_emit_b(w, (hit[i] - 1) & 1, 1, on && hit[i] > 0);
+        hv_emit_b(w, rem[i] & 31, 5, on && !ishit);
     }
     hv_emit(w, HV_CT(CX_UVPM, 0), 1);
     hv_emit(w, HV_CT(CX_SPLIT_TU + (5 - lg), kind == 1), kind != 2);
@@ -551,9 +586,9 @@ template <int MAXG = 9, typename WR> static HD int hv_tokenize_tu(const HvLds &S
     const int nx = ggx > 3 ? ((ggx - 2) >> 1) : 0, ny = ggy > 3 ? ((ggy - 2) >> 1) : 0;   /* suffix bits, one chunk per bit */
     tx -= hv_last_min(ggx); ty -= hv_last_min(ggy);
 #pragma unroll
-    for (int i = 2; i >= 0; i--) if (MAXG > 3) hv_emit(w, HV_TOK_BYP | (1 << 8) | ((tx >> i) & 1), on0 && i < nx);   /* groups <= 3 have no suffix */
+    for (int i = 2; i >= 0; i--) if (MAXG > 3) hv_emit_b(w, (tx >> i) & 1, 1, on0 && i < nx);   /* groups <= 3 have no suffix */
 #pragma unroll
-    for (int i = 2; i >= 0; i--) if (MAXG > 3) hv_emit(w, HV_TOK_BYP | (1 << 8) | ((ty >> i) & 1), on0 && i < ny);
+    for (int i = 2; i >= 0; i--) if (MAXG > 3) hv_emit_b(w, (ty >> i) & 1, 1, on0 && i < ny);
     hv_tok_checkpoint(w);
     return hv_tok_finish(w);
 }
@@ -579,6 +614,7 @@ static HD int hv_sigtab_index(int n, int kind, int nb, int first_cg) {
 }
 /* bypass bins of length len (<= 24) as <= 3 chunks of <= 8 from the top, exactly like hv_tok_byp  [ref :899-911] */
 template <typename WR> static HD void hv_emit_byp(WR &w, int bins, int len, int on) {
+    if constexpr (WR::fast) { w.byp += on ? len : 0; return; }
     bins &= (1 << len) - 1;
     const int n1 = hv_min(len, 8), r1 = len - n1, n2 = hv_min(r1, 8), n3 = r1 - n2;
     hv_emit(w, HV_TOK_BYP | (n1 << 8) | ((bins >> r1) & ((1 << n1) - 1)), on && n1 > 0);
@@ -597,6 +633,7 @@ template <typename WR> static HD void hv_emit_remainder(WR &w, int v, int k, int
     const int len = 31 - hv_clz((unsigned)w2), u = w2 - (1 << len);
     const int plen = shortf ? (v >> k) + 1 : 4 + len - k, pbins = (1 << plen) - 2;
     const int slen = shortf ? k : len, sbins = shortf ? (v & ((1 << k) - 1)) : u;
+    if constexpr (WR::fast) { w.byp += on ? plen + slen : 0; return; }
     const int simple = (plen <= 8) & (slen <= 8);
     hv_emit(w, HV_TOK_BYP | (plen << 8) | (pbins & 0xff), on && simple);
     hv_emit(w, HV_TOK_BYP | (slen << 8) | (sbins & 0xff), on && simple && slen > 0);
@@ -845,6 +882,124 @@ static HD int hv_engine_slots(const HvLds &S, HvCod &c, u8 *cx, const HV_GLOBAL 
         }
     }
     return dead;
+}
+
+/* --------------------------------------------------------------------------------------------- */
+/* FAST engines: the RANGE HALF of the arithmetic coder only.                                                                */
+/*                                                                                                                            */
+/* What a trial encode contributes to a decision is its bit count, CABAClen(trial) - CABAClen(entry)  [ref :835-837, 1438].   */
+/* Every renormalisation shift takes a bit out of `nbits` and every finished byte puts eight back while counting a byte, so    */
+/* that difference is  (sum of the renormalisation shifts) + (number of bypass bins) + 8 x (emulation-prevention bytes put     */
+/* during the trial)  [ref :821-832, 859-879, 899-933].  The shifts depend on `range` and the context states alone -- `low`,   */
+/* the finished bytes and the 0xff / 0x00 bookkeeping only matter through the third term, which is zero except once in a few   */
+/* million bytes.  So the trial engines carry (range, shift count) and the contexts, NOTHING else: no `low`, no byte records,  */
+/* no bypass tokens (their bins are counted at binarisation).  Costs computed this way are lower bounds of the reference's,     */
+/* equal to them for every candidate without an emulation-prevention byte.  The decision taken is the reference's whenever the  */
+/* WINNER has none: it then has the reference's cost, every other candidate has at least its own bound, and among equal bounds  */
+/* the later candidate was taken as the reference does.  The stream writer (hv_wr_*) encodes the chosen syntax exactly and      */
+/* reports every emulation-prevention byte it inserts, and hv_verify_nxn() does the same for the winners of the NxN sub-search  */
+/* (fresh coders): a CTU in which one occurred is analysed again with the EXACT engines above (hv_analyse_image).               */
+/* --------------------------------------------------------------------------------------------- */
+struct HvFCod { int range, nbits; };                         /* nbits only ever goes down: bits so far = start - nbits */
+struct HvFA { int tok; u8 *cp; unsigned lps4, nx; };         /* token j  : table entry of (context byte, bin) fetched */
+struct HvFB { int tok; u8 *cp; int cvl; };                   /* token j+1: raw context byte, read BEFORE token j's write-back */
+/* One chunk (8 bins) through the range coder, software-pipelined like hv_engine_chunk: while bin j goes through the registers
+   the context byte of bin j+2 and the table entry of bin j+1 are in flight.  Per bin: the LPS range is a byte of the entry
+   picked by the range quarter (one v_perm_b32: range >> 6 is 4..7, which selects a byte of its first operand), the new range
+   is `lps` or `range - lps` shifted left until bit 8 is set again  [ref :914-933]. */
+static HD void hv_fengine_chunk(const HvLds &S, HvFCod &c, u8 *cx, const HvChunk &cur, const HvChunk &nxt, HvFA &A, HvFB &B) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int ncv = (int)(A.nx & 0xff);
+        *A.cp = (u8)ncv;
+        const int cvb = (B.cp == A.cp) ? ncv : B.cvl;
+        const int ib = (cvb << 1) | ((B.tok >> 14) & 1);
+        const unsigned bl = S.ctab2[ib][0], bn = S.ctab2[ib][1];
+        const int tc = hv_chunk_tok(cur, nxt, j + 2);
+        u8 *cpc = cx + (tc & 0x1fff);
+        const int cvlc = *cpc;
+        const int lps = (int)hv_perm(A.lps4, 0u, (unsigned)c.range >> 6);
+        const int rm = c.range - lps;
+        const int pre = (A.nx >> 8) ? lps : rm;
+        const int sh = hv_clz_nz((unsigned)pre) - 23;
+        c.range = pre << sh;
+        c.nbits -= sh;
+        A.tok = B.tok; A.cp = B.cp; A.lps4 = bl; A.nx = bn;
+        B.tok = tc; B.cp = cpc; B.cvl = cvlc;
+    }
+}
+static HD void hv_fengine_prime(const HvLds &S, u8 *cx, const HvChunk &first, HvFA &A, HvFB &B) {
+    A.tok = (int)(first[0] & 0xffffu);
+    A.cp = cx + (A.tok & 0x1fff);
+    const int ia = (*A.cp << 1) | ((A.tok >> 14) & 1);
+    A.lps4 = S.ctab2[ia][0]; A.nx = S.ctab2[ia][1];
+    B.tok = (int)(first[0] >> 16);
+    B.cp = cx + (B.tok & 0x1fff);
+    B.cvl = *B.cp;
+}
+/* contiguous stream of n bins at sp, followed by at least 8 no-op bins (the NxN sub-search's streams in LDS) */
+template <typename ChunkPtr>
+static HD void hv_fengine(const HvLds &S, HvFCod &c, u8 *cx, ChunkPtr sp, int n) {
+    if (n <= 0) return;
+    HvChunk nxt = sp[0];
+    HvFA A; HvFB B;
+    hv_fengine_prime(S, cx, nxt, A, B);
+    for (int base = 0; base < n; base += 8) {
+        const HvChunk cur = nxt;
+        nxt = sp[(base >> 3) + 1];
+        hv_fengine_chunk(S, c, cx, cur, nxt, A, B);
+    }
+}
+/* over a candidate's slots in HBM; same contract as hv_engine_slots.  bits so far = bitsbase - c.nbits (bitsbase = the entry
+   snapshot's nbits + the candidate's bypass bins, which are all known beforehand and so sharpen the pruning from the start) */
+static HD int hv_fengine_slots(const HvLds &S, HvFCod &c, u8 *cx, const HV_GLOBAL u16 *slots, const HV_LDSP u16 *ls, int nlist, int &k, int &ci,
+                               int dead, int *shared, int notify, int q, int sse, int bitsbase, int *best) {
+    int e = ls[hv_min(k, nlist - 1)];
+    int nch = e >> 8;
+    const HV_GLOBAL HvChunk *ptr = (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HV_SLOT + HV_SLOT_TOK0) + ci;
+    HvChunk nxt = *ptr;
+    int it = 0, pub = 0;
+    HvFA A; HvFB B;
+    hv_fengine_prime(S, cx, nxt, A, B);
+    for (;;) {
+        const int done = dead || k >= nlist;
+        if (done && !pub) {                                       /* once, at the moment the lane finishes */
+            pub = 1;
+            if (!dead && best) hv_atomic_min(best, hv_rdcost(q, sse, bitsbase - c.nbits));
+            if (notify) hv_atomic_dec(shared);
+        }
+        if (shared ? (hv_poll(shared) <= 0) : done) break;
+        if (!done) {
+            const HvChunk cur = nxt;
+            ci++;
+            const int adv = ci >= nch;
+            k += adv;
+            e = ls[hv_min(k, nlist - 1)];
+            ci = adv ? 0 : ci;
+            nch = adv ? (e >> 8) : nch;
+            ptr = adv ? (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HV_SLOT + HV_SLOT_TOK0) : ptr + 1;
+            nxt = *ptr;
+            hv_fengine_chunk(S, c, cx, cur, nxt, A, B);
+            it++;
+            if (best && !(it & 1) && hv_rdcost(q, sse, bitsbase - c.nbits) > hv_peek(best)) dead = 1;
+        }
+    }
+    return dead;
+}
+/* single bins on the committed coder  [ref :914-933, 882-896] */
+static HD void hv_fbin(const HvLds &S, HvFCod &c, u8 *cx, int bin) {
+    const int v = *cx, st = v >> 1, mps = v & 1;
+    const int lps = (int)((S.lps4[st] >> (((c.range >> 6) & 3) << 3)) & 0xff);
+    const int islps = (bin != 0) != (mps != 0);
+    const int pre = islps ? lps : c.range - lps;
+    const int sh = hv_clz_nz((unsigned)pre) - 23;
+    c.range = pre << sh; c.nbits -= sh;
+    *cx = (u8)(islps ? (st == 0 ? (mps ^ 1) : ((S.lpsnext[st] << 1) | mps)) : (st < 62 ? v + 2 : v));
+}
+static HD void hv_fterminate(HvFCod &c, int bin) {
+    c.range -= 2;
+    if (bin) { c.range = 256; c.nbits -= 7; }
+    else if (c.range < 256) { c.range <<= 1; c.nbits--; }
 }
 
 /* --------------------------------------------------------------------------------------------- */
@@ -1475,13 +1630,14 @@ static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int 
 }
 
 /* NxN job (8x8 CU only): per 4x4 sub-block choose the mode with a fresh coder and fresh contexts  [ref :1499-1528] */
+template <bool FAST>
 static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c70) {
     HvLds &S = HV_S;
     HvLds::Level &L = S.lv[0];
     q = hv_uni(q); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x);
     int total = 0;
     HV_PROF2_T0();
-    if (lane == 0) S.c70_len = 16;
+    if (lane == 0) { S.c70_len = 16; S.c70_byp = 0; }
     for (int s = 0; s < 4; s++) {
         int l, lb, a, ar;
         hv_sub_avail(s, cu.L, cu.LB, cu.A, cu.AR, l, lb, a, ar);
@@ -1523,28 +1679,36 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
             for (int k = 0; k < 9; k++) *HV_CX(CX_SIG + k) = S.ctx_fresh[CX_SIG + k];
             for (int k = 0; k < 4; k++) *HV_CX(CX_ONE + k) = S.ctx_fresh[CX_ONE + k];
             *HV_CX(CX_ABS) = S.ctx_fresh[CX_ABS];
-            *HV_CX(HEVCE_NCTXP - 1) = 0;                          /* pad context used by bypass / no-op tokens */
-            HvCod c;
-            hv_cod_fresh(c);
+            *HV_CX(HV_CT_PAD) = HV_PADCV;                         /* pad context used by bypass / no-op tokens */
             HV_LDSP u16 *tk = (HV_LDSP u16 *)S.nxn_tok[lane];
             const int ks = hv_scan_kind(4, lane);
             /* the two slots are laid out so that their tokens are contiguous from tk[8]; one group: no set memory */
-            HvTokW<HV_LDSP u16 *> wa = { tk, 0 };
+            HvTokW<HV_LDSP u16 *, FAST> wa = { tk, 0, 0 };
             const int na = hv_tokenize_tu<3>(S, wa, 4, 2, ks, 0, 0, 1, S.nxn_last[lane]);
-            HvTokW<HV_LDSP u16 *> wb = { tk + na, 0 };
+            HvTokW<HV_LDSP u16 *, FAST> wb = { tk + na, 0, 0 };
             HvCg g;
             hv_cg_load(S, g, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0), 1);
             const int nb = hv_cg_emit(S, wb, g, 0);
 #pragma unroll
-            for (int i = 0; i < 8; i++) tk[HV_SLOT_TOK0 + na + nb + i] = (u16)HV_TOK_NOP;
+            for (int i = 0; i < 8; i++) tk[HV_SLOT_TOK0 + na + nb + i] = (u16)(FAST ? HV_TOK_NOPF : HV_TOK_NOP);
             HV_PROF2(S, 1);
             /* last block, only its engine to go: tell the candidates riding in the other wavefronts to wind up, so that they are
                at the workgroup barrier when this wavefront gets there */
             if (s == 3 && lane == 0) hv_flag_clear(&S.nxn_busy);
-            hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb, (HV_LDSP u16 *)S.nxn_sink[lane]);
-            hv_cod_replay(c, (const HV_LDSP HvChunk *)S.nxn_sink[lane]);
-            S.nxn_ntok[lane] = na + nb;
-            cost = hv_rdcost(q, S.nxn_sse[lane], hv_cod_bits(c));
+            int bits;
+            if constexpr (FAST) {
+                HvFCod c = { 510, 23 };
+                hv_fengine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb);
+                bits = 23 - c.nbits + wa.byp + wb.byp;
+            } else {
+                HvCod c;
+                hv_cod_fresh(c);
+                hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb, (HV_LDSP u16 *)S.nxn_sink[lane]);
+                hv_cod_replay(c, (const HV_LDSP HvChunk *)S.nxn_sink[lane]);
+                bits = hv_cod_bits(c);
+            }
+            S.nxn_ntok[lane] = (na + nb) | ((wa.byp + wb.byp) << 8) | (bits << 20);
+            cost = hv_rdcost(q, S.nxn_sse[lane], bits);
             idx = lane;
         }
         HV_PROF2(S, 2);
@@ -1565,13 +1729,20 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
         /* candidate 70 = the four winners: its token stream in HBM is [CU header, 16 tokens reserved][per block: cbf_luma,
            then -- if the block has levels -- exactly the winner's tokens of above], contiguous, no slot padding */
         {
-            const int off = S.c70_len, cbf = S.nxn_sig[w], n = cbf ? S.nxn_ntok[w] : 0;
+            const int pk = S.nxn_ntok[w];
+            const int off = S.c70_len, cbf = S.nxn_sig[w], n = cbf ? (pk & 0xff) : 0;
             const HV_LDSP u16 *src = (const HV_LDSP u16 *)S.nxn_tok[w] + HV_SLOT_TOK0;
             if (lane == 0) c70[off] = (u16)HV_CT(CX_YCBF, cbf);
             if (lane < n) c70[off + 1 + lane] = src[lane];
             if (lane + 64 < n) c70[off + 65 + lane] = src[lane + 64];
+            if constexpr (FAST) {
+                /* kept for hv_verify_nxn: the winner's levels, what the tokeniser was given, the bit count it was chosen with */
+                const int blk = (((cu.y >> 3) * 4 + (cu.x >> 3)) << 2) | s;
+                if (lane < 16) S.nxv_lev[blk][lane] = S.nxn_lev[w][lane];
+                if (lane == 0) { S.nxv_info[blk] = (u16)(S.nxn_last[w] | (hv_scan_kind(4, w) << 4) | (cbf << 6)); S.nxv_bits[blk] = (short)(pk >> 20); }
+            }
             WAVE_SYNC();
-            if (lane == 0) S.c70_len = off + 1 + n;
+            if (lane == 0) { S.c70_len = off + 1 + n; S.c70_byp += cbf ? ((pk >> 8) & 0xfff) : 0; }
         }
         WAVE_SYNC();
         HV_PROF2(S, 3);
@@ -1587,13 +1758,13 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
         pm.left[1] = pm.mode[0];  pm.above[1] = S.map_pm[my - 1][mx + 1];
         pm.left[2] = S.map_pm[my + 1][mx - 1];  pm.above[2] = pm.mode[0];
         pm.left[3] = pm.mode[2];  pm.above[3] = pm.mode[1];
-        HvTokW<HV_GLOBAL u16 *> wh = { c70 - HV_SLOT_TOK0, 0 };
+        HvTokW<HV_GLOBAL u16 *, FAST> wh = { c70 - HV_SLOT_TOK0, 0, 0 };
         const int nh = hv_tokenize_cu(wh, 8, 3, 2, L.split_inc, pm);
-        for (int k = nh; k < 16; k++) c70[k] = (u16)HV_TOK_NOP;
+        for (int k = nh; k < 16; k++) c70[k] = (u16)(FAST ? HV_TOK_NOPF : HV_TOK_NOP);
         const int len = S.c70_len;
-        for (int k = len; k < ((len + 7) & ~7); k++) c70[k] = (u16)HV_TOK_NOP;
+        for (int k = len; k < ((len + 7) & ~7); k++) c70[k] = (u16)(FAST ? HV_TOK_NOPF : HV_TOK_NOP);
         S.slist0[70][0] = (u16)(((len + 7) >> 3) << 8);          /* slot 0, that many chunks */
-        L.tlen[70] = 1; L.tpos[70] = 0; L.tnlog[70] = 0;
+        L.tlen[70] = 1; L.tpos[70] = 0; L.tnlog[70] = FAST ? S.c70_byp + wh.byp : 0;   /* FAST: tnlog = the candidate's bypass bins */
         L.tregs[70] = S.ent[0];
     }
     for (int r = lane; r < HEVCE_NCTXP; r += 64) L.tctx[r][70] = S.ent_ctx[0][r];
@@ -1613,12 +1784,62 @@ static HD void hv_job_sse(HvLds &S, int lane, const HvCu &cu) {
 
 /* one context-coded bin on the committed coder (split_cu_flag = 1 of a parent)  [ref :1404] */
 static HD void hv_commit_bin(HvLds &S, int ctx, int bin) {
-    HvCod c;
-    hv_cod_load(c, S.com);
     u8 tmp = S.com_ctx[ctx];
-    hv_bin(S, c, &tmp, bin);
+    if (S.exact) {
+        HvCod c;
+        hv_cod_load(c, S.com);
+        hv_bin(S, c, &tmp, bin);
+        hv_cod_store(S.com, c);
+    } else {
+        HvFCod c = { S.com.range, S.com.nbits };
+        hv_fbin(S, c, &tmp, bin);
+        S.com.range = c.range; S.com.nbits = c.nbits;
+    }
     S.com_ctx[ctx] = tmp;
-    hv_cod_store(S.com, c);
+}
+/* end_of_slice_segment_flag on the committed coder  [ref :1630] */
+static HD void hv_commit_terminate(HvLds &S, int bin) {
+    if (S.exact) {
+        HvCod c;
+        hv_cod_load(c, S.com);
+        hv_terminate(c, bin);
+        hv_cod_store(S.com, c);
+    } else {
+        HvFCod c = { S.com.range, S.com.nbits };
+        hv_fterminate(c, bin);
+        S.com.range = c.range; S.com.nbits = c.nbits;
+    }
+}
+
+/* The winners of the CTU's 64 NxN sub-searches once more, each through an EXACT fresh coder  [ref :1505-1519]: lane = 4x4
+   block.  The binarisation is the tokenisers' -- with a "writer" that sends every bin straight through the coder -- so the
+   bit count can only differ from the FAST engine's by the emulation-prevention bytes; any difference poisons the CTU.
+   One wavefront, at the end of a FAST CTU (the chain's context columns are free then). */
+struct HvTokExec { const HvLds *S; HvCod c; u8 *cx; int n; enum { fast = 0 }; };
+static HD void hv_emit(HvTokExec &w, int tok, int on) {
+    if (on) {
+        if (tok & HV_TOK_BYP) hv_bypass(w.c, tok & 0xff, (tok >> 8) & 15);
+        else hv_bin(*w.S, w.c, w.cx + (tok & 0x1fff), (tok >> 14) & 1);
+    }
+}
+static HD void hv_tok_checkpoint(HvTokExec &) { }
+static HD int  hv_tok_finish(HvTokExec &) { return 0; }
+static HDN void hv_verify_nxn(int lane) {
+    HvLds &S = HV_S;
+    u8 *cx = &S.nxn_ctx[0][lane];
+    for (int k = 0; k < 3; k++) { *HV_CX(CX_LASTX + k) = S.ctx_fresh[CX_LASTX + k]; *HV_CX(CX_LASTY + k) = S.ctx_fresh[CX_LASTY + k]; }
+    for (int k = 0; k < 9; k++) *HV_CX(CX_SIG + k) = S.ctx_fresh[CX_SIG + k];
+    for (int k = 0; k < 4; k++) *HV_CX(CX_ONE + k) = S.ctx_fresh[CX_ONE + k];
+    *HV_CX(CX_ABS) = S.ctx_fresh[CX_ABS];
+    const int info = S.nxv_info[lane], last = info & 15, ks = (info >> 4) & 3, sig = (info >> 6) & 1;
+    HvTokExec w;
+    w.S = &S; w.cx = cx; w.n = 0;
+    hv_cod_fresh(w.c);
+    hv_tokenize_tu<3>(S, w, 4, 2, ks, 0, 0, 1, last);
+    HvCg g;
+    hv_cg_load(S, g, (const HV_LDSP short *)S.nxv_lev[lane], 4, 2, ks, 0, last, (u64)sig, 1);
+    hv_cg_emit(S, w, g, 0);
+    if (hv_cod_bits(w.c) != S.nxv_bits[lane]) S.poison = 1;
 }
 
 /* --------------------------------------------------------------------------------------------- */
@@ -1663,6 +1884,7 @@ static HD const HV_LDSP u16 *hv_slist(const HvLds &S, int lvl, int t) { return l
 /* Group item number `item` (candidate-major, coding order inside a transform block).  EVERY lane of the wavefront calls
    this (valid = 0 beyond the last item): the groups of one transform block sit in adjacent lanes, aligned to their
    count, so the "previous coded group had a level > 1" memory  [ref :1222-1226] is two wave-wide ballots away. */
+template <bool FAST>
 static HD void hv_bin_group(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, HvGLev glev, const HvCnt &cn, int item, int valid) {
     const int ncg_cu = (cu.n >> 2) * (cu.n >> 2);
     item = valid ? item : 0;
@@ -1681,26 +1903,21 @@ static HD void hv_bin_group(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL
     if (!valid) return;
     HV_LDSP u8 &sh = hv_cnt(cn, t, 1 + tu * (1 + ncgt) + 1 + r);
     if (!cbf) { sh = 0; return; }
-    HvTokRing w = hv_tok_ring(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt) + 1 + r) * HV_SLOT);
+    HvTokRingT<FAST> w = hv_tok_ring<FAST>(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt) + 1 + r) * HV_SLOT);
     sh = (u8)hv_cg_emit(S, w, g, g1);
+    if (FAST) hv_atomic_add(&L.tnlog[t], w.byp);
 }
-static HD void hv_bin_group_nxn(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, const HvCnt &cn, int tu) {   /* candidate 70: levels in LDS */
-    const int t = 70;
-    HV_LDSP u8 &sh = hv_cnt(cn, t, 1 + tu * 2 + 1);
-    if (!L.tinfo[t][tu].cbf) { sh = 0; return; }
-    HvTokRing w = hv_tok_ring(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * 2 + 1) * HV_SLOT);
-    HvCg g;
-    hv_cg_load(S, g, (const HV_LDSP short *)&S.nxn_bestlev[tu][0], 4, 2, hv_scan_kind(4, S.nxn_modes[tu]), 0, L.tinfo[t][tu].last, L.tinfo[t][tu].cgsig, 1);
-    sh = (u8)hv_cg_emit(S, w, g, 0);
-}
+template <bool FAST>
 static HD void hv_bin_tu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, const HvCnt &cn, int t, int tu) {
     const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
     const int tn = kind == 0 ? cu.n : (cu.n >> 1), tlg = kind == 0 ? cu.lg : cu.lg - 1, ncgt = (tn >> 2) * (tn >> 2);
     const int md = kind == 0 ? t : kind == 1 ? t - 35 : S.nxn_modes[tu];
-    HvTokRing w = hv_tok_ring(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt)) * HV_SLOT);
+    HvTokRingT<FAST> w = hv_tok_ring<FAST>(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt)) * HV_SLOT);
     hv_cnt(cn, t, 1 + tu * (1 + ncgt)) = (u8)hv_tokenize_tu(S, w, tn, tlg, hv_scan_kind(tn, md), 1, kind == 0 ? CX_YCBF + 1 : CX_YCBF,
                                                          L.tinfo[t][tu].cbf, L.tinfo[t][tu].last);
+    if (FAST) hv_atomic_add(&L.tnlog[t], w.byp);
 }
+template <bool FAST>
 static HD void hv_bin_cu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL u16 *gtok, const HvCnt &cn, int t) {
     const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
     const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
@@ -1715,12 +1932,13 @@ static HD void hv_bin_cu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GL
         pm.left[2] = S.map_pm[my + 1][mx - 1];  pm.above[2] = pm.mode[0];
         pm.left[3] = pm.mode[2];  pm.above[3] = pm.mode[1];
     }
-    HvTokRing w = hv_tok_ring(S, gtok + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT);
+    HvTokRingT<FAST> w = hv_tok_ring<FAST>(S, gtok + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT);
     hv_cnt(cn, t, 0) = (u8)hv_tokenize_cu(w, cu.n, cu.lg, kind, L.split_inc, pm);
+    if (FAST) hv_atomic_add(&L.tnlog[t], w.byp);
 }
 
 /* link: the list of candidate t's non-empty slots; the engine walks it */
-static HD void hv_build_slist(HvLds &S, HvLds::Level &L, const HvCnt &cn, int n, int lvl, int t) {
+static HD void hv_build_slist(HvLds &S, HvLds::Level &L, const HvCnt &cn, int n, int lvl, int t, int fast) {
     const int nslots = hv_trial_slots(n, t);
     HV_LDSP u16 *ls = hv_slist(S, lvl, t);
     int k = 0;
@@ -1729,7 +1947,8 @@ static HD void hv_build_slist(HvLds &S, HvLds::Level &L, const HvCnt &cn, int n,
         ls[k] = (u16)(f | (ch << 8));
         k += (ch != 0);
     }
-    L.tlen[t] = k; L.tpos[t] = 0; L.tnlog[t] = 0;
+    L.tlen[t] = k; L.tpos[t] = 0;
+    if (!fast) L.tnlog[t] = 0;                                   /* FAST: tnlog holds the candidate's bypass bins */
 }
 
 /* candidates of a 16x16 / 32x32 CU start from its entry snapshot  [ref :1423-1424]: context columns and coder registers
@@ -1750,8 +1969,11 @@ static HD void hv_level_contexts(HvLds &S, const HevceImageDesc &im, const HvCu 
    shared == nullptr: everything selected runs to its end.  Otherwise *shared is a count that other lanes / wavefronts bring
    to zero, and the candidates ride along until it gets there (8x8 candidates, if selected, run to their end and are the
    ones that count it down). */
-static HD void hv_run_engines(HvLds &S, const HevceImageDesc &im, int mask, int *shared, int nw, int ew) {
-    const int lane = hv_tid() & 63, q = im.qpd6;
+static HDN void hv_run_engines(HV_GLOBAL u8 *scratch, int q, int mask, int *shared, int nw, int ew) {
+    HvLds &S = HV_S;
+    const int lane = hv_tid() & 63;
+    q = hv_uni(q); mask = hv_uni(mask); nw = hv_uni(nw); ew = hv_uni(ew);
+    const int fast = !hv_uni(S.exact);
     const int per = HV_TL / nw;
     const int lvl = lane / per, t = (lane % per) * nw + ew;
     if (ew >= 0 && lvl < 3 && ((mask >> lvl) & 1)) {
@@ -1760,31 +1982,34 @@ static HD void hv_run_engines(HvLds &S, const HevceImageDesc &im, int mask, int 
         if (t < ntrials && L.tpos[t] >= 0) {
             const int pos = L.tpos[t], nlist = L.tlen[t];
             int k = pos & 0xff, ci = pos >> 8;
-            HvCod c;
-            hv_cod_load(c, L.tregs[t]);
-            const int bits0 = hv_regs_bits(S.ent[lvl]);
-            const HV_GLOBAL u16 *slots = (const HV_GLOBAL u16 *)(hv_level_scratch(im, lvl) + HV_TL * 1024 * 3) + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT;
-            HV_GLOBAL u16 *sink = (HV_GLOBAL u16 *)(hv_level_scratch(im, lvl) + HV_TL * 1024 * 3 + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT * 2) + (size_t)t * HEVCE_SINK_WORDS;
-            int dead = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0) > hv_peek(&L.best_cost);
-            hv_cod_span(c);
-            const int nlog = L.tnlog[t];                          /* the records stay: they are the candidate's bytes, should it win */
-#ifdef HEVCE_PROF_ENG
-            const unsigned long long e0_ = __builtin_amdgcn_s_memtime();
-#endif
-            dead = hv_engine_slots(S, c, &L.tctx[0][t], slots, hv_slist(S, lvl, t), nlist, k, ci, dead, shared,
-                                   shared && lvl == 0, q, L.tsse[t], bits0, &L.best_cost, sink + nlog);
-#ifdef HEVCE_PROF_ENG
-            const unsigned long long e1_ = __builtin_amdgcn_s_memtime();
-#endif
-            L.tnlog[t] = nlog + c.nev;
-            hv_cod_replay(c, (const HV_GLOBAL HvChunk *)sink, nlog);
-#ifdef HEVCE_PROF_ENG
-            if (nw == 4 && shared && t == 70 && lvl == 0) { S.prof2[16] += e1_ - e0_; S.prof2[17] += __builtin_amdgcn_s_memtime() - e1_; S.prof2[18] += nlist ? (S.slist0[70][0] >> 8) : 0; }
-#endif
-            hv_cod_store(L.tregs[t], c);
+            HV_GLOBAL u8 *lscr = scratch + (size_t)lvl * HEVCE_SCRATCH_LEVEL_BYTES;
+            const HV_GLOBAL u16 *slots = (const HV_GLOBAL u16 *)(lscr + HV_TL * 1024 * 3) + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT;
+            int dead, cost;
+            if (fast) {
+                HvFCod c = { L.tregs[t].range, L.tregs[t].nbits };
+                const int bitsbase = S.ent[lvl].nbits + L.tnlog[t];
+                dead = hv_rdcost(q, L.tsse[t], bitsbase - c.nbits) > hv_peek(&L.best_cost);
+                dead = hv_fengine_slots(S, c, &L.tctx[0][t], slots, hv_slist(S, lvl, t), nlist, k, ci, dead, shared,
+                                        shared && lvl == 0, q, L.tsse[t], bitsbase, &L.best_cost);
+                L.tregs[t].range = c.range; L.tregs[t].nbits = c.nbits;
+                cost = hv_rdcost(q, L.tsse[t], bitsbase - c.nbits);
+            } else {
+                HvCod c;
+                hv_cod_load(c, L.tregs[t]);
+                const int bits0 = hv_regs_bits(S.ent[lvl]);
+                HV_GLOBAL u16 *sink = (HV_GLOBAL u16 *)(lscr + HV_TL * 1024 * 3 + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT * 2) + (size_t)t * HEVCE_SINK_WORDS;
+                dead = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0) > hv_peek(&L.best_cost);
+                hv_cod_span(c);
+                const int nlog = L.tnlog[t];                      /* EXACT: tnlog = byte records in the sink so far */
+                dead = hv_engine_slots(S, c, &L.tctx[0][t], slots, hv_slist(S, lvl, t), nlist, k, ci, dead, shared,
+                                       shared && lvl == 0, q, L.tsse[t], bits0, &L.best_cost, sink + nlog);
+                L.tnlog[t] = nlog + c.nev;
+                hv_cod_replay(c, (const HV_GLOBAL HvChunk *)sink, nlog);
+                hv_cod_store(L.tregs[t], c);
+                cost = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0);
+            }
             if (dead) { L.tdead[t] = 1; L.tcost[t] = HV_I32MAX; L.tpos[t] = -1; }
             else if (k >= nlist) {
-                const int cost = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0);
                 L.tcost[t] = cost;
                 L.tpos[t] = -1;
                 hv_atomic_min(&L.best_cost, cost);
@@ -1796,20 +2021,11 @@ static HD void hv_run_engines(HvLds &S, const HevceImageDesc &im, int mask, int 
    wavefronts on one SIMD would take turns).  finish = 0: the 8x8 candidates run to their end, the candidates of the
    enclosing CUs ride along for as long as that takes (S.l0_active counts the 8x8 engines still running);
    finish = 1 (a 16x16 / 32x32 CU is decided): what the ride-along left runs to its end. */
-static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int finish, int ctu = 0) {
+static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int finish) {
     const int wave = hv_tid() >> 6;
     HV_PROF_T0();
-#ifdef HEVCE_PROF_ENG
-    const unsigned long long p0_ = __builtin_amdgcn_s_memtime();
-#endif
-    hv_run_engines(S, im, mask, finish ? nullptr : &S.l0_active, 4, wave < 4 ? wave : -1);
-#ifdef HEVCE_PROF_ENG
-    const unsigned long long p1_ = __builtin_amdgcn_s_memtime();
-#endif
+    hv_run_engines((HV_GLOBAL u8 *)im.scratch, im.qpd6, mask, finish ? nullptr : &S.l0_active, 4, wave < 4 ? wave : -1);
     BLOCK_SYNC();
-#ifdef HEVCE_PROF_ENG
-    if (!finish && hv_tid() == 128) { S.prof2[19] += p1_ - p0_; S.prof2[20] += __builtin_amdgcn_s_memtime() - p1_; S.prof2[21] += 1; }
-#endif
     HV_PROF(S, 0, 6);
 }
 
@@ -1817,15 +2033,18 @@ static HD void hv_engine_phase(HvLds &S, const HevceImageDesc &im, int mask, int
    lists: nothing here depends on another wavefront, so it happens in the shadow of the NxN chain without any
    synchronisation.  Group items: 64 / (groups per CU) candidates per pass, lane = candidate * groups + group (the groups of
    one transform block in adjacent, aligned lanes: see hv_bin_group). */
-static HD void hv_bin_own(HvLds &S, const HevceImageDesc &im, const HvCu cu, int tb, int tc) {
+template <bool FAST>
+static HDN void hv_bin_own(HV_GLOBAL u8 *scr, HvCu cu, int tb, int tc) {
+    HvLds &S = HV_S;
     const int lane = hv_tid() & 63;
+    cu.lvl = hv_uni(cu.lvl); cu.n = hv_uni(cu.n); cu.lg = hv_uni(cu.lg); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x);
     HvLds::Level &L = S.lv[cu.lvl];
-    HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
     HV_GLOBAL u16 *gtok = (HV_GLOBAL u16 *)(scr + HV_TL * 1024 * 3);
     const int ncg = (cu.n >> 2) * (cu.n >> 2), per = 64 / ncg;
     tb = hv_uni(tb); tc = hv_uni(tc);
     /* slot counts of these (<= 16) candidates: behind the token ring in this wavefront's scratch tile */
     const HvCnt cn = { (HV_LDSP u8 *)&S.ws[hv_tid() >> 6] + 4096, tb };
+    if (FAST && lane < tc) L.tnlog[tb + lane] = 0;               /* FAST: the work items add up the candidate's bypass bins here */
     HV_FENCE_RELEASE();                                          /* the jobs' levels in HBM, their results in LDS */
     WAVE_SYNC();
 #ifdef HEVCE_PROF_BIN
@@ -1835,17 +2054,17 @@ static HD void hv_bin_own(HvLds &S, const HevceImageDesc &im, const HvCu cu, int
 #define HV_BINT(i) do { } while (0)
 #endif
     for (int c0 = 0; c0 < tc; c0 += per)
-        hv_bin_group(S, L, cu, gtok, (HvGLev)scr, cn, (tb + c0 + lane / ncg) * ncg + lane % ncg, c0 + lane / ncg < tc);
+        hv_bin_group<FAST>(S, L, cu, gtok, (HvGLev)scr, cn, (tb + c0 + lane / ncg) * ncg + lane % ncg, c0 + lane / ncg < tc);
     HV_BINT(0);
     for (int j = lane; j < tc * 4; j += 64) {
         const int t = tb + (j >> 2), tu = j & 3;
-        if (t >= 35 || tu == 0) hv_bin_tu_header(S, L, cu, gtok, cn, t, tu);
+        if (t >= 35 || tu == 0) hv_bin_tu_header<FAST>(S, L, cu, gtok, cn, t, tu);
     }
     HV_BINT(1);
-    for (int j = lane; j < tc; j += 64) hv_bin_cu_header(S, L, cu, gtok, cn, tb + j);
+    for (int j = lane; j < tc; j += 64) hv_bin_cu_header<FAST>(S, L, cu, gtok, cn, tb + j);
     WAVE_SYNC();
     HV_BINT(2);
-    for (int j = lane; j < tc; j += 64) hv_build_slist(S, L, cn, cu.n, cu.lvl, tb + j);
+    for (int j = lane; j < tc; j += 64) hv_build_slist(S, L, cn, cu.n, cu.lvl, tb + j, FAST);
     HV_BINT(3);
 }
 
@@ -2163,21 +2382,24 @@ static HDN void hv_wr_slice(const HevceImageDesc &im, int cw, int r) {
      3. in the time the NxN chain still takes, the prepared candidates of the enclosing CUs ride on.
    The schedule is static and wave-uniform (SGPRs): no lane-dependent control flow may surround the jobs (wave shuffles). */
 #define HV_JOBT(slot, call) call
-static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m, int ctu) {
+static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m, int ctu, int wr_on) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
     const int wv = hv_uni(wave);
+    const int fast = !hv_uni(S.exact);
     k16 = hv_uni(k16); m = hv_uni(m);
     HV_GLOBAL u8 *s0 = hv_level_scratch(im, 0), *s1 = hv_level_scratch(im, 1), *s2 = hv_level_scratch(im, 2);
     if (wv == 0) {
         /* the NxN chain; it also writes the token stream, slot list and engine state of its outcome, candidate 70, and
            clears S.nxn_busy shortly before its end */
-        hv_job_nxn(wave, lane, q, c8, (HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3) + (size_t)70 * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0);
+        HV_GLOBAL u16 *c70 = (HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3) + (size_t)70 * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0;
+        if (fast) hv_job_nxn<true>(wave, lane, q, c8, c70);
+        else hv_job_nxn<false>(wave, lane, q, c8, c70);
         return;
     }
     if (wv == 4) {
         /* shares its SIMD with wavefront 0, so no jobs: one of its lanes writes the previous CTU's slice data instead (slice = this
            round's 8x8 position); the older wavefront 0 wins the SIMD's issue arbitration */
-        if (im.payload && ctu > 0) {
+        if (wr_on) {
             if (k16 == 0 && m == 0) { hv_wr_stage(S, im, ctu - 1); WAVE_SYNC(); }
             if (lane == 0) hv_wr_slice(im, ctu - 1, k16 * 4 + m);
         }
@@ -2192,7 +2414,10 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         HV_JOBT(9, hv_job_single<8>(wave, lane, q, c8, 2 * (w1 - 3), l0, r0));
         if (w1 < 5) HV_JOBT(9, hv_job_single<8>(wave, lane, q, c8, 2 * (w1 - 3) + 1, l0, r0));
     }
-    hv_bin_own(S, im, c8, w1 < 3 ? 35 + 16 * w1 : 16 * (w1 - 3), hv_min(16, (w1 < 3 ? 70 : 35) - (w1 < 3 ? 35 + 16 * w1 : 16 * (w1 - 3))));
+    {
+        const int tb = w1 < 3 ? 35 + 16 * w1 : 16 * (w1 - 3), tc = hv_min(16, (w1 < 3 ? 70 : 35) - tb);
+        if (fast) hv_bin_own<true>(s0, c8, tb, tc); else hv_bin_own<false>(s0, c8, tb, tc);
+    }
     {   /* the 8x8 candidates' engines start from the CU's entry snapshot  [ref :1423-1424] */
         HvLds::Level &L0 = S.lv[0];
         const int t6 = w1 * 64 + lane;
@@ -2221,9 +2446,11 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
        lanes per CU level and job wavefront, until wavefront 0 clears S.nxn_busy (16x16 candidates exist from their CU's
        second round on, 32x32 candidates after round (1,2)) */
     /* the 16x16 CU's candidates (their jobs ran in the previous round): twelve per job wavefront, any wavefront will do */
-    if (m == 1) hv_bin_own(S, im, c16, 12 * w1, hv_min(12, 70 - 12 * w1));
-    if (k16 == 1 && m == 3) hv_bin_own(S, im, c32, 12 * w1, hv_min(12, 70 - 12 * w1));    /* the 32x32 CU's: its last jobs ran in round (1,2) */
-    hv_run_engines(S, im, (m >= 2 ? 2 : 0) | (k16 >= 2 ? 4 : 0), &S.nxn_busy, 6, w1);
+    if (m == 1) { if (fast) hv_bin_own<true>(s1, c16, 12 * w1, hv_min(12, 70 - 12 * w1)); else hv_bin_own<false>(s1, c16, 12 * w1, hv_min(12, 70 - 12 * w1)); }
+    if (k16 == 1 && m == 3) {                                    /* the 32x32 CU's: its last jobs ran in round (1,2) */
+        if (fast) hv_bin_own<true>(s2, c32, 12 * w1, hv_min(12, 70 - 12 * w1)); else hv_bin_own<false>(s2, c32, 12 * w1, hv_min(12, 70 - 12 * w1));
+    }
+    hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, (m >= 2 ? 2 : 0) | (k16 >= 2 ? 4 : 0), &S.nxn_busy, 6, w1);
 }
 
 static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, HevceRecord *rec, int32_t *dump) {
@@ -2277,7 +2504,7 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
     if (w < 0) return;                                          /* the four sub-CUs stay */
 
     /* ---------------- commit the winner: coder, contexts, reconstruction, maps, record ---------------- */
-    if (tid == 0) S.com = L.tregs[w];
+    if (tid == 0) { S.com = L.tregs[w]; if (!S.exact) S.com.nbits -= L.tnlog[w]; }   /* FAST: the winner's bypass bins are bits of the stream too */
     if (tid < HEVCE_NCTXP) S.com_ctx[tid] = L.tctx[tid][w];
     const int kindw = w < 35 ? 0 : (w < 70 ? 1 : 2);
     for (int p = tid; p < n * n; p += HV_NTHREADS) {
@@ -2313,12 +2540,6 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
 static HD void hv_init_tables(HvLds &S, int q, int tid) {
     if (tid < 64) { S.lps4[tid] = hv_lps4[tid]; S.lpsnext[tid] = hv_lpsnext[tid]; }
     if (tid >= 384 && tid < 384 + 35) { S.ang[tid - 384] = hv_ang[tid - 384]; S.invang[tid - 384] = hv_invang[tid - 384]; }
-    if (tid >= 256 && tid < 384) {
-        const int cv = tid - 256, st = cv >> 1, mps = cv & 1;
-        const int nm = st < 62 ? cv + 2 : cv, nl = st == 0 ? (mps ^ 1) : ((hv_lpsnext[st] << 1) | mps);
-        S.ctab[cv][0] = hv_lps4[st];
-        S.ctab[cv][1] = (unsigned)(nl | (nm << 8));
-    }
     if (tid == 64) {
         /* up-right diagonal order inside a 4x4 group and over 2x2 / 4x4 / 8x8 groups  [ref :1130-1132] */
         int k = 0;
@@ -2336,9 +2557,29 @@ static HD void hv_init_tables(HvLds &S, int q, int tid) {
         int st = ((((iv >> 4) * 5 - 45) * qp) >> 4) + ((iv & 15) << 3) - 16;
         st = hv_min(hv_max(st, 1), 126);
         const u8 v = (u8)(st >= 64 ? (((st - 64) << 1) | 1) : ((63 - st) << 1));
-        S.ctx_fresh[i] = v; S.com_ctx[i] = v; S.wr_ctx[i] = v;
+        S.ctx_fresh[i] = v; S.com_ctx[i] = (i == HV_CT_PAD) ? (u8)HV_PADCV : v; S.wr_ctx[i] = v;
     }
     if (tid == 300) { S.com.range = 510; S.com.low = 0; S.com.nbits = 23; S.com.nbytes = 0; S.com.bufbyte = 0xff; S.com.zeros = 0; S.com.nout = 0; S.com.pad = 0; S.wr = S.com; S.wr_epb = 0; }
+}
+
+/* The engines' context table for the mode the workgroup is in (EXACT: ctab, FAST: ctab2 -- they share their LDS).  All threads;
+   needs a barrier before the next engine runs  [ref :701-713, 914-933]. */
+static HD void hv_set_mode(HvLds &S, int exact, int tid) {
+    if (exact) {
+        if (tid < 128) {
+            const int cv = tid, st = cv >> 1, mps = cv & 1;
+            const int nm = st < 62 ? cv + 2 : cv, nl = st == 0 ? (mps ^ 1) : ((hv_lpsnext[st] << 1) | mps);
+            S.ctab[cv][0] = hv_lps4[st];
+            S.ctab[cv][1] = (unsigned)(nl | (nm << 8));
+        }
+    } else if (tid < 256) {
+        const int cv = tid >> 1, bin = tid & 1, st = cv >> 1, mps = cv & 1, islps = bin != mps;
+        const int nm = st < 62 ? cv + 2 : cv, nl = st == 0 ? (mps ^ 1) : ((hv_lpsnext[st] << 1) | mps);
+        const int real = st < 63;                                /* context bytes 126 / 127 (state 63) never occur: 126 is the pad context */
+        S.ctab2[tid][0] = real ? hv_lps4[st] : 0u;
+        S.ctab2[tid][1] = real ? (unsigned)((islps ? nl : nm) | (islps << 8)) : (unsigned)cv;
+    }
+    if (tid == 0) S.exact = exact;
 }
 
 /* second init step (after the scan tables exist): significance-context tables  [ref :1092-1122 evaluated per position] */
@@ -2360,6 +2601,36 @@ static HD void hv_snapshot(HvLds &S, int lvl, int tid) {
     if (tid < HEVCE_NCTXP) S.ent_ctx[lvl][tid] = S.com_ctx[tid];
 }
 
+/* the writer does a whole CTU in one go (wavefront 4; the others wait at the caller's barrier) */
+static HD void hv_wr_whole(HvLds &S, const HevceImageDesc &im, int cw) {
+    if ((hv_tid() >> 6) == 4) {
+        hv_wr_stage(S, im, cw);
+        WAVE_SYNC();
+        if (hv_tid() == 4 * 64) for (int r = 0; r < 16; r++) hv_wr_slice(im, cw, r);
+    }
+}
+/* CTU `ctu` starts from here (the committed coder and contexts, what it reads of its left neighbour and of the CTU row above) */
+static HD void hv_snap_take(HvLds &S, int ctu, int x0, int tid) {
+    HvLds::Snap &P = S.snap[ctu & 1];
+    if (tid == 0) P.com = S.com;
+    if (tid < HEVCE_NCTXP) P.com_ctx[tid] = S.com_ctx[tid];
+    if (tid >= 128 && tid < 136) { P.map_cu8[tid - 128] = S.map_cu[1 + tid - 128][8]; P.map_pm8[tid - 128] = S.map_pm[1 + tid - 128][8]; P.line_cu[tid - 128] = S.line_cu[(x0 >> 2) + tid - 128]; }
+    if (tid >= 192 && tid < 224) P.rec_col[tid - 192] = S.rec[1 + tid - 192][HV_RX + 31];
+}
+static HD void hv_snap_restore(HvLds &S, int ctu, int x0, int tid) {
+    const HvLds::Snap &P = S.snap[ctu & 1];
+    if (tid == 0) S.com = P.com;
+    if (tid < HEVCE_NCTXP) S.com_ctx[tid] = P.com_ctx[tid];
+    if (tid >= 128 && tid < 136) { S.map_cu[1 + tid - 128][8] = P.map_cu8[tid - 128]; S.map_pm[1 + tid - 128][8] = P.map_pm8[tid - 128]; S.line_cu[(x0 >> 2) + tid - 128] = P.line_cu[tid - 128]; }
+    if (tid >= 192 && tid < 224) S.rec[1 + tid - 192][HV_RX + 31] = P.rec_col[tid - 192];
+}
+
+/* The picture: CTUs in raster order, analysed with the FAST engines while the writer (one CTU behind) produces the bytes.
+   A CTU whose decisions the FAST bit counts cannot vouch for -- the writer put an emulation-prevention byte while encoding it,
+   or one of its NxN winners would have had one -- is POISONED: the workgroup goes back to that CTU's start, analyses it with
+   the EXACT engines, lets the writer encode it in one go, and carries on FAST.  A few CTUs per 4K picture.
+   im.flags (tests): bit 0 = EXACT throughout; bits 8-15 = poison every k-th CTU as an NxN winner would, bits 16-23 = as the
+   writer would (each CTU once). */
 static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int tid = hv_tid(), q = im.qpd6, H = im.H, W = im.W;
     if (tid == 0) S.trace = im.trace;
@@ -2373,15 +2644,28 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     BLOCK_SYNC();
     HV_TRACE(S, 0, 1);
     hv_init_tables(S, q, tid);
+    const int force_exact = (im.flags & 1) || !im.payload;      /* without the writer nothing vouches for the FAST decisions */
+    const int pk_nxn = (im.flags >> 8) & 0xff, pk_wr = (im.flags >> 16) & 0xff;
+    hv_set_mode(S, force_exact, tid);
+    if (tid == 0) { S.poison = 0; S.wr_done = 0; }
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
     BLOCK_SYNC();
-    int ctu = 0;
-    for (int y0 = 0; y0 < H; y0 += 32) {
-        for (int x0 = 0; x0 < W; x0 += 32, ctu++) {
+    const int ncx = W >> 5, nctu = ncx * (H >> 5);
+    int ctu = 0, redone = -1, n_redo = 0, n_bad = 0;            /* redone: the CTU most recently analysed twice (test hooks fire once) */
+    for (;;) {
+        const int exact = hv_uni(S.exact);
+        const int tail = ctu == nctu;                            /* past the last CTU: only the writer has work left */
+        const int wr_on = im.payload && ctu > 0 && hv_uni(S.wr_done) < ctu;   /* the writer does CTU ctu - 1 during this round */
+        const int y0 = (ctu / ncx) * 32, x0 = (ctu % ncx) * 32;
+        if (wr_on && tid == 4 * 64) { S.wsnap = S.wr; S.wr_epb = 0; }
+        if (wr_on && (tid >> 6) == 4) for (int i = tid & 63; i < HEVCE_NCTXP; i += 64) S.wsnap_ctx[i] = S.wr_ctx[i];
+        if (tail) { if (wr_on) hv_wr_whole(S, im, ctu - 1); }
+        else {
             HevceRecord *rec = (HevceRecord *)(im.records + (size_t)ctu * HEVCE_REC_BYTES);
             HV_TRACE(S, 0, 1000 + ctu);
             const int L = x0 > 0, A = y0 > 0, AR = A && (x0 + 32 < W);
+            hv_snap_take(S, ctu, x0, tid);
             /* ---- load the CTU: source samples (edge-replicated), neighbours, maps  [ref :1611-1622] ---- */
             for (int p = tid; p < 1024; p += HV_NTHREADS) {
                 const int yy = hv_min(y0 + (p >> 5), im.src_h - 1), xx = hv_min(x0 + (p & 31), im.src_w - 1);
@@ -2443,7 +2727,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
 #ifdef HEVCE_PROF_JDUR
                     const unsigned long long j0_ = __builtin_amdgcn_s_memtime();
 #endif
-                    hv_jobs_phase(S, im, cu, c16, c32, k, m, ctu);
+                    hv_jobs_phase(S, im, cu, c16, c32, k, m, ctu, wr_on);
 #ifdef HEVCE_PROF_JDUR
                     if (tid == HEVCE_PROF_JDUR * 64) S.prof2[16 + k * 4 + m] += __builtin_amdgcn_s_memtime() - j0_;   /* that wavefront's jobs phase, riders included */
 #endif
@@ -2457,36 +2741,71 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     HV_PROF(S, 0, 0);
                     if (m == 0) hv_level_contexts(S, im, c16);
                     if (k == 1 && m == 2) hv_level_contexts(S, im, c32);     /* its jobs ran in five phases up to this one */
-                    hv_engine_phase(S, im, 1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0), 0, ctu);
+                    hv_engine_phase(S, im, 1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0), 0);
                 }
                 hv_decide_cu(S, im, cu, ctu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr);
             }
 
-            /* ---- end of CTU: terminate bin, publish reconstruction and line buffers  [ref :1626-1637] ---- */
-            if (tid == 0) {
-                HvCod c;
-                hv_cod_load(c, S.com);
-                hv_terminate(c, (y0 + 32 >= H) && (x0 + 32 >= W));
-                hv_cod_store(S.com, c);
-                if (im.ctu_state && !im.payload) {               /* without the stream writer: the analysis' own coder registers */
-                    int32_t *st = im.ctu_state + (size_t)ctu * 8;
-                    st[0] = c.range; st[1] = (int32_t)c.low; st[2] = c.nbits; st[3] = c.nbytes; st[4] = c.bufbyte; st[5] = c.zeros;
-                    st[6] = c.nout; st[7] = hv_cod_bits(c);
-                }
-            }
-            for (int p = tid; p < 1024; p += HV_NTHREADS)
-                im.rcon[(size_t)(y0 + (p >> 5)) * W + x0 + (p & 31)] = S.rec[1 + (p >> 5)][HV_RX + (p & 31)];
+        }
+        BLOCK_SYNC();
+        /* ---- is everything decided so far the reference's decision?  (FAST only; see hv_fengine_chunk) ---- */
+        if (!tail && !exact && (tid >> 6) == 4) hv_verify_nxn(tid & 63);
+        BLOCK_SYNC();
+        const int chk_range = tail ? S.com.range : S.snap[ctu & 1].com.range;     /* the analysis' range where the writer now stands */
+        const int bad_wr = wr_on && S.wr.range != chk_range;                       /* must never happen: counted, and healed like a poisoned CTU */
+        const int p_wr = wr_on && (S.wr_epb > 0 || bad_wr || (pk_wr && (ctu - 1) % pk_wr == pk_wr - 1 && redone != ctu - 1));
+        const int p_nxn = !tail && !exact && (S.poison || (pk_nxn && ctu % pk_nxn == pk_nxn - 1 && redone != ctu));
+        BLOCK_SYNC();
+        if (p_wr || p_nxn) {
+            /* back to the start of the poisoned CTU (the previous one if the writer objected), EXACT this time; the EXACT coder
+               continues from the writer's registers at that point */
+            n_redo++; n_bad += bad_wr;
+            if (p_wr) {
+                ctu--;
+                if (tid == 0) S.wr = S.wsnap;
+                if (tid < HEVCE_NCTXP) S.wr_ctx[tid] = S.wsnap_ctx[tid];
+            } else if (wr_on && tid == 0) S.wr_done = ctu;
             BLOCK_SYNC();
-            if (tid >= 64 && tid < 72) S.line_cu[(x0 >> 2) + tid - 64] = S.map_cu[8][1 + tid - 64];
+            hv_snap_restore(S, ctu, (ctu % ncx) * 32, tid);
+            BLOCK_SYNC();
+            if (tid == 0) { S.com = S.wr; S.poison = 0; }
+            hv_set_mode(S, 1, tid);
+            redone = ctu;
+            BLOCK_SYNC();
+            continue;
+        }
+        if (wr_on && tid == 0) S.wr_done = ctu;
+        if (tail) break;
+        /* ---- end of CTU: terminate bin, publish reconstruction and line buffers  [ref :1626-1637] ---- */
+        if (tid == 0) {
+            hv_commit_terminate(S, ctu == nctu - 1);
+            if (im.ctu_state && !im.payload) {                   /* without the stream writer: the analysis' own coder registers */
+                int32_t *st = im.ctu_state + (size_t)ctu * 8;
+                const HevceCoderRegs &c = S.com;
+                st[0] = c.range; st[1] = (int32_t)c.low; st[2] = c.nbits; st[3] = c.nbytes; st[4] = c.bufbyte; st[5] = c.zeros;
+                st[6] = c.nout; st[7] = hv_regs_bits(c);
+            }
+        }
+        for (int p = tid; p < 1024; p += HV_NTHREADS)
+            im.rcon[(size_t)(y0 + (p >> 5)) * W + x0 + (p & 31)] = S.rec[1 + (p >> 5)][HV_RX + (p & 31)];
+        BLOCK_SYNC();
+        if (tid >= 64 && tid < 72) S.line_cu[(x0 >> 2) + tid - 64] = S.map_cu[8][1 + tid - 64];
+        BLOCK_SYNC();
+        if (exact && im.payload) {
+            /* an EXACT CTU is written at once: the writer's registers are what the next FAST or EXACT CTU is checked against */
+            hv_wr_whole(S, im, ctu);
+            BLOCK_SYNC();
+            if (tid == 0) {
+                S.wr_done = ctu + 1;
+                const HevceCoderRegs &a = S.com, &b = S.wr;
+                if (ctu != nctu - 1) n_bad += a.range != b.range || a.low != b.low || a.nbits != b.nbits || a.nbytes != b.nbytes || a.bufbyte != b.bufbyte || a.zeros != b.zeros || a.nout != b.nout;
+            }
+            if (!force_exact) hv_set_mode(S, 0, tid);
             BLOCK_SYNC();
         }
+        ctu++;
     }
-    /* the last CTU's slice data and the coder's tail: nothing left to overlap it with */
-    if (im.payload && (tid >> 6) == 4) {
-        hv_wr_stage(S, im, ctu - 1);
-        WAVE_SYNC();
-        if (tid == 4 * 64) for (int r = 0; r < 16; r++) hv_wr_slice(im, ctu - 1, r);
-    }
+    if (im.stats && tid == 0) { im.stats[0] = n_redo; im.stats[1] = n_bad; }
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     if (im.trace && tid < 24) { ((unsigned long long *)im.trace)[tid] = (&S.prof[0][0])[tid]; }
     if (im.trace && tid < 32) { ((unsigned long long *)im.trace)[24 + tid] = S.prof2[tid]; }

@@ -53,7 +53,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 struct Image {
     int h0, w0, H, W, q, nctu;
     size_t off_img, off_rcon, off_rec, off_state, off_scratch;   /* into the device slab */
-    size_t off_payload, off_leadlog, off_plen;                   /* device-side byte emission: slice data, byte log, length */
+    size_t off_payload, off_plen, off_stats;                     /* the kernel's stream writer: slice data, its length; re-analysis statistics */
     size_t hoff_rec, hoff_state, hoff_plen;                      /* into the pinned host slab */
     const void *ext_img = nullptr;
     long ext_stride = 0;                                         /* row stride of ext_img (0: w0) */
@@ -72,6 +72,7 @@ struct hevce_job {
     std::vector<HevceImageDesc> h_desc;
     bool desc_dirty = true, launched = false;
     bool device_emit = true;         /* the kernel emits the slice data itself; HEVCE_HOST_WRITER=1: replay the records on the host instead */
+    int flags = 0;                   /* HevceImageDesc.flags (tests: HEVCE_FLAGS) */
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     float kernel_ms = 0, d2h_ms = 0, writer_ms = 0;
@@ -109,8 +110,8 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
         m.off_state = d;   d = align256(d + size_t(m.nctu) * 32);
         m.off_scratch = d; d = align256(d + HEVCE_SCRATCH_BYTES);
         m.off_payload = d; d = align256(d + size_t(m.nctu) * 3200 + 64);
-        m.off_leadlog = d; d = align256(d + size_t(2) * HEVCE_LEADLOG_WORDS * 2);
         m.off_plen = d;    d = align256(d + 4);
+        m.off_stats = d;   d = align256(d + 8);
         m.hoff_rec = h;    h = align256(h + size_t(m.nctu) * HEVCE_REC_BYTES);
         m.hoff_state = h;  h = align256(h + size_t(m.nctu) * 32);
         m.hoff_plen = h;   h = align256(h + 4);
@@ -124,6 +125,7 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
     if (!ok) { fail("hevce_job_create: device allocation failed (%zu bytes HBM, %zu bytes pinned)", d, h); hevce_job_destroy(j); return nullptr; }
     j->stream = j->own_stream;
     j->device_emit = getenv("HEVCE_HOST_WRITER") == nullptr;
+    if (const char *e = getenv("HEVCE_FLAGS")) j->flags = (int)strtol(e, nullptr, 0);
     if (getenv("HEVCE_DUMP")) {
         for (int i = 0; i < n; i++) j->dump_ints += size_t(j->im[i].nctu) * 21 * HEVCE_TRIALS * 16;
         if (hipMalloc((void **)&j->d_dump, j->dump_ints * 4) != hipSuccess) j->d_dump = nullptr;
@@ -192,6 +194,18 @@ int hevce_job_set_stream(hevce_job *j, void *s) {
     return 0;
 }
 
+int hevce_job_set_flags(hevce_job *j, int flags) {
+    if (!j) return fail("hevce_job_set_flags: null job");
+    j->flags = flags; j->desc_dirty = true;
+    return 0;
+}
+int hevce_job_stats(hevce_job *j, int i, int *out2) {
+    if (!j || i < 0 || i >= j->n || !out2) return fail("hevce_job_stats: bad arguments");
+    HIPCHK(hipSetDevice(j->device));
+    HIPCHK(hipMemcpy(out2, j->d_slab + j->im[i].off_stats, 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int hevce_job_launch(hevce_job *j) {
     if (!j) return fail("hevce_job_launch: null job");
     HIPCHK(hipSetDevice(j->device));
@@ -210,7 +224,8 @@ int hevce_job_launch(hevce_job *j) {
             d.src_h = m.h0; d.src_w = m.w0; d.src_stride = (m.ext_img && m.ext_stride) ? m.ext_stride : m.w0; d.H = m.H; d.W = m.W; d.qpd6 = m.q; d.status = 0;
             d.trace = j->h_trace ? j->h_trace + 1024 * i : nullptr;
             d.payload = j->device_emit ? j->d_slab + m.off_payload : nullptr;
-            d.leadlog = j->device_emit ? (uint16_t *)(j->d_slab + m.off_leadlog) : nullptr;
+            d.stats = (int32_t *)(j->d_slab + m.off_stats);
+            d.flags = j->flags; d.pad_ = 0;
             d.payload_len = j->device_emit ? (int32_t *)(j->d_slab + m.off_plen) : nullptr;
         }
         HIPCHK(hipMemcpyAsync(j->d_desc, j->h_desc.data(), sizeof(HevceImageDesc) * j->n, hipMemcpyHostToDevice, j->stream));

@@ -79,6 +79,13 @@ int  hevce_job_download_records(hevce_job *job, int i, unsigned char *records, i
 /* timings of the last run, milliseconds: kernel (HIP events on the launch stream), D2H wait, stream assembly on the host */
 int  hevce_job_timings(hevce_job *job, float *kernel_ms, float *d2h_ms, float *writer_ms);
 
+/* The kernel analyses with range-only ("FAST") trial coders and re-analyses with the exact ones the few CTUs whose bit counts
+   an emulation-prevention byte could have changed; stats: out2[0] = CTUs of image i analysed twice in the last
+   run, out2[1] = coder consistency failures (always 0).  flags (tests): bit 0 = exact coders throughout, bits 8-15 / 16-23 =
+   force a re-analysis every k-th CTU through either detection path. */
+int  hevce_job_set_flags(hevce_job *job, int flags);
+int  hevce_job_stats(hevce_job *job, int i, int *out2);
+
 /* diagnostics and function-level test hooks */
 int  hevce_test_tu(const unsigned char *org32x32, const unsigned char *nbr33x65, int n, int qpd6, int aL, int aLB, int aA, int aAR,
                    short *lev35x1024, unsigned char *rec35x1024, int *info35x4);

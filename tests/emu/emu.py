@@ -28,7 +28,7 @@ def lib():
     return _lib
 
 
-def analyse(img, q, want_dump=False):
+def analyse(img, q, want_dump=False, flags=0):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
     H, W = (min(h, 8192) + 31) // 32 * 32, (min(w, 8192) + 31) // 32 * 32
@@ -39,9 +39,11 @@ def analyse(img, q, want_dump=False):
     dump = np.zeros((nctu, 21, 72, 16), np.int32) if want_dump else None
     payload = np.zeros(nctu * 3200 + 64, np.uint8)
     plen = C.c_int32(-1)
+    stats = np.zeros(2, np.int32)
     rc = lib().emu_analyse(img.ctypes.data_as(_u8p), h, w, q, rcon.ctypes.data_as(_u8p), rec.ctypes.data_as(_u8p),
                            st.ctypes.data_as(C.POINTER(C.c_int32)), dump.ctypes.data_as(C.POINTER(C.c_int32)) if want_dump else None,
-                           payload.ctypes.data_as(_u8p), C.byref(plen))
+                           payload.ctypes.data_as(_u8p), C.byref(plen), flags, stats.ctypes.data_as(C.POINTER(C.c_int32)))
     assert rc == 0, "emulator deadlock"
+    analyse.stats = stats
     analyse.payload = bytes(payload[:max(plen.value, 0)])          # the slice data the device emitted itself
     return (rec, rcon, st, dump) if want_dump else (rec, rcon, st)

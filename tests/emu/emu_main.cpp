@@ -65,13 +65,13 @@ void emu_block_sync(void) {
 
 extern "C" __attribute__((visibility("default")))
 int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, uint8_t *records, int32_t *ctu_state, int32_t *dump,
-                uint8_t *payload, int32_t *payload_len) {
+                uint8_t *payload, int32_t *payload_len, int flags, int32_t *stats) {
     HevceImageDesc im;
     memset(&im, 0, sizeof im);
     im.img = img; im.rcon = rcon; im.records = records; im.ctu_state = ctu_state;
     im.dump = dump;
-    std::vector<uint16_t> leadlog(2 * HEVCE_LEADLOG_WORDS, 0xABCD);
-    if (payload) { im.payload = payload; im.payload_len = payload_len; im.leadlog = leadlog.data(); }     /* device-side byte emission on */
+    if (payload) { im.payload = payload; im.payload_len = payload_len; }     /* the kernel's stream writer on */
+    im.flags = flags; im.stats = stats;
     im.src_h = src_h; im.src_w = src_w; im.src_stride = src_w; im.qpd6 = q;
     im.H = ((src_h < HEVCE_MAXDIM ? src_h : HEVCE_MAXDIM) + 31) / 32 * 32;
     im.W = ((src_w < HEVCE_MAXDIM ? src_w : HEVCE_MAXDIM) + 31) / 32 * 32;

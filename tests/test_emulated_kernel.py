@@ -38,3 +38,22 @@ def test_emulated_kernel_on_black_and_white_noise(orc, q):
     assert np.array_equal(rcon, orcon) and np.array_equal(st, ost) and np.array_equal(rec, orec)
     stream, _ = orc.encode(img, q)
     assert stream.endswith(emu.analyse.payload) and len(emu.analyse.payload) > 0
+
+
+MODE_CASES = [p for p in small_cases() if any(k in p for k in ("lcg_100x70_q2", "g2_16_64x96_q0", "g2_16_64x96_q4", "checker_64x64_q2"))]
+
+
+@pytest.mark.parametrize("flags", [1, 2 << 8, 3 << 16, (1 << 8) | (1 << 16), (3 << 8) | (2 << 16)],
+                         ids=["exact", "nxn2", "wr3", "every-ctu-both", "nxn3-wr2"])
+@pytest.mark.parametrize("path", MODE_CASES, ids=lambda p: os.path.basename(p)[6:-4])
+def test_emulated_kernel_reanalysis_paths(path, flags):
+    """FAST analysis + EXACT re-analysis of poisoned CTUs (hevce_device.h, hv_analyse_image): the test hooks poison CTUs
+    the way an NxN winner / the writer would; the output must stay the golden one and the two coders must never disagree."""
+    import emu
+    c = load_case(path)
+    rec, rcon, st = emu.analyse(c["img"], c["q"], flags=flags)
+    assert np.array_equal(rcon, c["rcon"]) and np.array_equal(st, c["ctu_state"]) and np.array_equal(rec, c["records"])
+    assert bytes(c["stream"]).endswith(emu.analyse.payload) and len(emu.analyse.payload) > 0
+    redo, bad = emu.analyse.stats
+    assert bad == 0
+    assert (redo > 0) == (flags != 1)

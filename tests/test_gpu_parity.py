@@ -49,6 +49,30 @@ def test_records_and_states_match_oracle(hevce, orc):
             assert job.stream(0) == orc.write_stream(orec, orcon.shape[0], orcon.shape[1], q)
 
 
+@pytest.mark.parametrize("flags", [1, 2 << 8, 3 << 16, (1 << 8) | (1 << 16), (5 << 8) | (7 << 16)],
+                         ids=["exact", "nxn2", "wr3", "every-ctu-both", "nxn5-wr7"])
+def test_fast_analysis_and_exact_reanalysis_paths(hevce, orc, flags):
+    """The kernel decides with range-only trial coders and re-analyses poisoned CTUs with the exact ones.  The test
+    hooks poison CTUs through both detection paths; streams, reconstruction, records and coder registers stay the oracle's and
+    the writer's coder never disagrees with the analysis' (stats[1] == 0)."""
+    import hevce_workload as wl
+    imgs = [wl.gen_g2(96, 160, 16, seed=4242), wl.gen_g2(70, 100, 4, seed=7), (np.random.RandomState(3).randint(0, 2, (64, 96)) * 255).astype(np.uint8)]
+    qs = [2, 0, 4]
+    with hevce.Job([im.shape for im in imgs], qs) as job:
+        job.set_flags(flags)
+        for i, im in enumerate(imgs):
+            job.upload(i, im)
+        job.run()
+        for i, im in enumerate(imgs):
+            s, r = orc.encode(im, qs[i])
+            orec, orcon, ost = orc.analyse(im, qs[i])
+            rec, st = job.records(i)
+            assert job.stream(i) == s and np.array_equal(job.rcon(i), r), i
+            assert np.array_equal(rec, orec) and np.array_equal(st, ost), i
+            redo, bad = job.stats(i)
+            assert bad == 0 and (redo > 0) == (flags != 1), (i, redo, bad)
+
+
 def test_batch_of_ragged_images(hevce, orc):
     """independent images of different sizes and qpd6 in ONE launch (one workgroup each)"""
     import hevce_workload as wl
