@@ -65,12 +65,14 @@ typedef struct HevceImageDesc {
     /* the kernel's stream writer: the slice data bytes.  payload == NULL: no writer; the analysis then runs
        with the EXACT engines throughout and the host replays the records (hevce_write_stream) */
     uint8_t       *payload;   /* out: the slice data bytes (what follows the VPS/SPS/PPS/slice header) */
+    uint8_t       *wr_tok;    /* HEVCE_WRTOK_BYTES: the token slots of the CTU the writer is encoding */
     int32_t       *payload_len;
     int32_t       *stats;     /* optional, 2 ints: CTUs analysed twice (EXACT after FAST), consistency failures (must be 0) */
     int32_t        flags;     /* tests: bit 0 EXACT engines throughout; bits 8-15 / 16-23: forced re-analysis periods (hevce_device.h) */
     int32_t        pad_;
 } HevceImageDesc;
 
+#define HEVCE_WRTOK_BYTES   (3 * 64 * HEVCE_TOKEN_SLOT_WORDS * 2)            /* CU header, block header, group slot per 4x4 position */
 #define HEVCE_TRIALS        72                               /* 35 + 35 + 1 (+1 pad) trial slots */
 #define HEVCE_TOKEN_SLOT_WORDS 128                           /* 16-bit words per bin-token slot */
 #define HEVCE_TOKEN_SLOTS      70                            /* slots per trial: CU header + block headers + 4x4 groups */

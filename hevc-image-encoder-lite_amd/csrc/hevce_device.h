@@ -21,6 +21,7 @@
 #define HV_GLOBAL
 #define HV_LDSP
 #define HV_KEEP(x) do { } while (0)
+#define HV_NOUNROLL
 static inline unsigned hv_ldg_u32(const unsigned *p) { return *p; }
 static inline unsigned hv_perm(unsigned a, unsigned b, unsigned sel) {
     const unsigned long long src = ((unsigned long long)a << 32) | b;
@@ -50,6 +51,7 @@ static inline void hv_atomic_add(int *p, int v) { *p += v; }
 #else
 #define BLOCK_SYNC() __syncthreads()
 #endif
+#define HV_NOUNROLL _Pragma("clang loop unroll(disable)")   /* one-lane code: compact beats unrolled (instruction cache) */
 #define HV_KEEP(x) asm volatile("" : "+v"(x))          /* pins the first use of a prefetched value to this point */
 #define HV_GLOBAL __attribute__((address_space(1)))    /* pointer known to address HBM: global_* instead of flat_* */
 #define HV_LDSP   __attribute__((address_space(3)))    /* pointer known to address LDS: ds_* instead of flat_* */
@@ -235,10 +237,13 @@ struct alignas(16) HvLds {
     /* the stream writer (wavefront 4, one lane): the exact byte-emitting coder of the FINAL syntax, one CTU behind the
        analysis; it re-derives the bins of the previous CTU's decision record  [ref :797-933, 943-1340 for the chosen syntax] */
     HevceCoderRegs wr;                                      /* range, low, nbits, pending bytes, held byte, zero run, bytes written */
-    u8  wr_ctx[HEVCE_NCTXP];
     int wr_epb;                                             /* emulation-prevention bytes inserted while writing the current CTU */
     u8  wr_linfo[8], wr_lmode[8], wr_ainfo[8];              /* CU size / mode of the 4x4 blocks left of and above the CTU being written */
     alignas(16) HevceRecord wr_rec;                         /* its decision record, staged from HBM */
+    struct WrSt {                                           /* where the writer's coder stands in that CTU's token slots (hv_wr_engine works in slices) */
+        int pos, ci, done;                                  /* next slot in coding order (3 per 4x4 z-position: CU header, block header, group), chunk inside it; CTU complete */
+        int total, budget;                                  /* chunks of the CTU, chunks per slice */
+    } wst;
 #ifdef HEVCE_ANYPROF
     unsigned long long prof[3][8];
     unsigned long long prof2[32];                           /* HEVCE_PROF: inside the NxN job (tu jobs, tokenise, engine, select) */
@@ -2076,9 +2081,9 @@ static HDN void hv_bin_own(HV_GLOBAL u8 *scr, HvCu cu, int tb, int tc) {
 /* It is sliced by 8x8 position: slice r (z-order) writes the CU whose origin is that position, so that it fits in the shadow */
 /* of the NxN chain of the analysis round r.                                                                                  */
 /* --------------------------------------------------------------------------------------------- */
-struct HvWr { int range; unsigned low; int nbits, pending, held, zeros, n, epb; HV_GLOBAL u8 *out; };
+struct HvWr { int range; unsigned low; int nbits, pending, held, zeros, n, epb; HV_GLOBAL u8 *out; int exact; };
 static HD HvWr hv_wr_load(const HvLds &S, const HevceImageDesc &im) {
-    HvWr w = { S.wr.range, S.wr.low, S.wr.nbits, S.wr.nbytes, S.wr.bufbyte, S.wr.zeros, S.wr.nout, S.wr_epb, (HV_GLOBAL u8 *)im.payload };
+    HvWr w = { S.wr.range, S.wr.low, S.wr.nbits, S.wr.nbytes, S.wr.bufbyte, S.wr.zeros, S.wr.nout, S.wr_epb, (HV_GLOBAL u8 *)im.payload, S.exact };
     return w;
 }
 static HD void hv_wr_store(HvLds &S, const HvWr &w) {
@@ -2105,20 +2110,24 @@ static HD void hv_wr_carry(HvWr &w) {                                           
         for (; w.pending > 1; w.pending--) hv_wr_put(w, fill);
     } else { w.pending = 1; w.held = lead; }                     /* first byte ever: stored unmasked, as the reference does */
 }
-static HD void hv_wr_bin(HvLds &S, HvWr &w, int ci, int bin) {                                              /* [ref :914-933] */
-    const int v = S.wr_ctx[ci], st = v >> 1, mps = v & 1;
-    const int lps = (int)((S.lps4[st] >> (((w.range >> 6) & 3) << 3)) & 0xff);
-    w.range -= lps;
-    if ((bin != 0) != (mps != 0)) {
-        const int sh = (lps < 8) ? 6 : hv_clz((unsigned)(lps >> 3)) - 26;
-        S.wr_ctx[ci] = (u8)(st == 0 ? (mps ^ 1) : ((S.lpsnext[st] << 1) | mps));
-        w.low = (w.low + (unsigned)w.range) << sh;
+static HD void hv_wr_bin(HvLds &S, HvWr &w, u8 *cp, int bin) {                                              /* [ref :914-933] */
+    /* two dependent LDS reads per bin -- the context byte, then the engines' table entry for it (whichever table the workgroup's
+       mode has built, hv_set_mode): the writer is bound by their latency, not by instructions */
+    const int v = *cp;
+    unsigned l4, nx;
+    int islps;
+    if (w.exact) { l4 = S.ctab[v][0]; const unsigned e = S.ctab[v][1]; islps = (bin ^ v) & 1; nx = (e >> (islps ? 0 : 8)) & 0xff; }
+    else { l4 = S.ctab2[(v << 1) | bin][0]; const unsigned e = S.ctab2[(v << 1) | bin][1]; islps = (int)(e >> 8); nx = e & 0xff; }
+    const int lps = (int)((l4 >> (((w.range >> 6) & 3) << 3)) & 0xff);
+    const int rm = w.range - lps;
+    *cp = (u8)nx;
+    if (islps) {
+        const int sh = hv_clz_nz((unsigned)lps) - 23;
+        w.low = (w.low + (unsigned)rm) << sh;
         w.range = lps << sh;
         w.nbits -= sh;
-    } else {
-        if (st < 62) S.wr_ctx[ci] = (u8)(v + 2);
-        if (w.range < 256) { w.low <<= 1; w.range <<= 1; w.nbits--; }
-    }
+    } else if (rm < 256) { w.low <<= 1; w.range = rm << 1; w.nbits--; }
+    else w.range = rm;
     hv_wr_carry(w);
 }
 static HD void hv_wr_bypass(HvWr &w, int bins, int len) {                                                  /* [ref :899-911] */
@@ -2145,182 +2154,12 @@ static HD void hv_wr_finish(HvWr &w) {                                          
     const int tail = (int)((w.low >> 8) << w.nbits);
     hv_wr_put(w, tail >> 16); hv_wr_put(w, tail >> 8); hv_wr_put(w, tail);
 }
-/* coeff_abs_level_remaining  [ref :1154-1169] */
-static HD void hv_wr_remainder(HvWr &w, int v, int k) {
-    if (v < (3 << k)) {
-        const int pre = v >> k;
-        hv_wr_bypass(w, (1 << (pre + 1)) - 2, pre + 1);
-        hv_wr_bypass(w, v & ((1 << k) - 1), k);
-    } else {
-        int len = k;
-        v -= 3 << k;
-        for (; v >= (1 << len); len++) v -= 1 << len;
-        hv_wr_bypass(w, (1 << (4 + len - k)) - 2, 4 + len - k);
-        hv_wr_bypass(w, v, len);
-    }
-}
-/* residual_coding of the n x n block at CTU-relative (y0, x0)  [ref putCoef :1173-1269]; the block is known to have a level */
-static HD void hv_wr_residual(HvLds &S, HvWr &w, int y0, int x0, int n, int lg, int mode) {
-    const int kind = hv_scan_kind(n, mode), ncg = n >> 2, ncgt = ncg * ncg;
-    const HV_LDSP short *lev = (const HV_LDSP short *)&S.wr_rec.lev[0][0];
-    /* which 4x4 groups hold a level (bit gy * 8 + gx), the last group in scan order that does, the last position inside it */
-    u64 cgsig = 0;
-    int cg_last = 0;
-    for (int cg = 0; cg < ncgt; cg++) {
-        int gy, gx;
-        hv_scan_cg(S, lg, kind, cg, gy, gx);
-        const HV_LDSP HvPair *row = (const HV_LDSP HvPair *)(lev + (y0 + gy * 4) * 32 + x0 + gx * 4);
-        const HvPair a = row[0], b = row[8], c = row[16], d = row[24];      /* four rows of four 16-bit levels, 64 bytes apart */
-        if ((a[0] | a[1] | b[0] | b[1] | c[0] | c[1] | d[0] | d[1]) != 0) { cgsig |= (u64)1 << (gy * 8 + gx); cg_last = cg; }
-    }
-    int c1 = 1, last = 0;
-    for (int cg = cg_last; cg >= 0; cg--) {
-        int gy, gx;
-        hv_scan_cg(S, lg, kind, cg, gy, gx);
-        const int first_cg = cg == 0, at_last = cg == cg_last;
-        const int cgs = (int)((cgsig >> (gy * 8 + gx)) & 1);
-        const int right = (gx < ncg - 1) ? (int)((cgsig >> (gy * 8 + gx + 1)) & 1) : 0;
-        const int below = (gy < ncg - 1) ? (int)((cgsig >> (gy * 8 + 8 + gx)) & 1) : 0;
-        const int nb = (below << 1) | right;
-        if (!cgs && !first_cg) { hv_wr_bin(S, w, CX_SIGCG + (nb != 0), 0); continue; }     /* never the last group: that one holds a level */
-        int v[16];
-        unsigned nzm = 0;
-#pragma unroll
-        for (int ii = 0; ii < 16; ii++) {
-            int iy, ix;
-            hv_scan_in(S, kind, ii, iy, ix);
-            v[ii] = lev[(y0 + gy * 4 + iy) * 32 + x0 + gx * 4 + ix];
-            nzm |= (unsigned)(v[ii] != 0) << ii;
-        }
-        int start = 15;
-        if (at_last) {
-            start = 31 - hv_clz(nzm);
-            last = (cg << 4) | start;
-            /* last_sig_coeff_x/y prefix and suffix  [ref :1046-1087]; for the vertical scan the coordinates swap */
-            int iy, ix;
-            hv_scan_in(S, kind, start, iy, ix);
-            const int y = gy * 4 + iy, x = gx * 4 + ix;
-            const int cls = lg - 2, sh = (n == 4) ? 0 : 1;
-            int ty = kind == 2 ? x : y, tx = kind == 2 ? y : x;
-            const int ggy = hv_last_group(ty), ggx = hv_last_group(tx), gmax = 2 * lg - 1;
-            for (int i = 0; i < ggx; i++) hv_wr_bin(S, w, CX_LASTX + 5 * cls + (i >> sh), 1);
-            if (ggx < gmax) hv_wr_bin(S, w, CX_LASTX + 5 * cls + (ggx >> sh), 0);
-            for (int i = 0; i < ggy; i++) hv_wr_bin(S, w, CX_LASTY + 5 * cls + (i >> sh), 1);
-            if (ggy < gmax) hv_wr_bin(S, w, CX_LASTY + 5 * cls + (ggy >> sh), 0);
-            if (ggx > 3) { tx -= hv_last_min(ggx); for (int i = ((ggx - 2) >> 1) - 1; i >= 0; i--) hv_wr_bypass(w, (tx >> i) & 1, 1); }
-            if (ggy > 3) { ty -= hv_last_min(ggy); for (int i = ((ggy - 2) >> 1) - 1; i >= 0; i--) hv_wr_bypass(w, (ty >> i) & 1, 1); }
-        } else if (!first_cg) hv_wr_bin(S, w, CX_SIGCG + (nb != 0), 1);
-        /* significance flags, highest scan position first; the last position itself is known, position 0 of a later group is
-           inferred when nothing else in the group is set  [ref :1194-1216] */
-        const u8 *tab = S.sigtab[hv_sigtab_index(n, kind, nb, first_cg)];
-        const int any_above0 = (nzm >> 1) != 0;
-#pragma unroll
-        for (int ii = 15; ii >= 0; ii--)
-            if (ii <= start && !(at_last && ii == start) && (ii != 0 || first_cg || any_above0))
-                hv_wr_bin(S, w, CX_SIG + tab[ii], (int)((nzm >> ii) & 1));
-        if (!nzm) continue;
-        /* greater1 flags of the first eight levels, one greater2 flag, signs, remainders  [ref :1218-1266] */
-        const int nz = __builtin_popcount(nzm);
-        const int set = (first_cg ? 0 : 2) + (c1 == 0);
-        int esc = nz > 8, g2 = -1, j = 0, signs = 0;
-        c1 = 1;
-#pragma unroll
-        for (int ii = 15; ii >= 0; ii--)
-            if ((nzm >> ii) & 1) {
-                const int a = hv_abs(v[ii]);
-                if (j < 8) {
-                    hv_wr_bin(S, w, CX_ONE + 4 * set + c1, a > 1);
-                    if (a > 1) { c1 = 0; if (g2 < 0) g2 = a > 2; else esc = 1; }
-                    else if (c1 > 0 && c1 < 3) c1++;
-                }
-                signs = (signs << 1) | (v[ii] < 0);
-                j++;
-            }
-        if (c1 == 0 && g2 >= 0) { hv_wr_bin(S, w, CX_ABS + set, g2); esc |= g2; }
-        hv_wr_bypass(w, signs, nz);
-        if (esc) {
-            int base = 3, rice = 0;
-            j = 0;
-#pragma unroll
-            for (int ii = 15; ii >= 0; ii--)
-                if ((nzm >> ii) & 1) {
-                    const int a = hv_abs(v[ii]), rem = a - (j < 8 ? base : 1);
-                    if (rem >= 0) {
-                        hv_wr_remainder(w, rem, rice);
-                        if (a > (3 << rice)) rice = hv_min(rice + 1, 4);
-                    }
-                    if (a >= 2) base = 2;
-                    j++;
-                }
-        }
-    }
-    (void)last;
-}
-static HD int hv_wr_nonzero(const HvLds &S, int y0, int x0, int n) {
-    const HV_LDSP short *lev = (const HV_LDSP short *)&S.wr_rec.lev[0][0];
-    unsigned any = 0;
-    for (int i = 0; i < n; i++)
-        for (int jx = 0; jx < n; jx += 4) {
-            const HvPair a = *(const HV_LDSP HvPair *)(lev + (y0 + i) * 32 + x0 + jx);
-            any |= a[0] | a[1];
-        }
-    return any != 0;
-}
 /* neighbour context of the CTU being written, with the reference's line-buffer semantics  [ref :1369-1373, 1595-1600, 1634-1637]:
    CU size 32 outside the picture; mode DC outside the picture and across a CTU-row boundary */
 static HD int hv_wr_cu_left(const HvLds &S, int L, int y, int x)  { return x > 0 ? 8 << (S.wr_rec.info[y >> 2][(x >> 2) - 1] & HEVCE_INFO_LOG2_MASK) : (L ? 8 << (S.wr_linfo[y >> 2] & HEVCE_INFO_LOG2_MASK) : 32); }
 static HD int hv_wr_cu_above(const HvLds &S, int A, int y, int x) { return y > 0 ? 8 << (S.wr_rec.info[(y >> 2) - 1][x >> 2] & HEVCE_INFO_LOG2_MASK) : (A ? 8 << (S.wr_ainfo[x >> 2] & HEVCE_INFO_LOG2_MASK) : 32); }
 static HD int hv_wr_pm_left(const HvLds &S, int L, int y, int x)  { return x > 0 ? S.wr_rec.mode[y >> 2][(x >> 2) - 1] : (L ? S.wr_lmode[y >> 2] : 1); }
 static HD int hv_wr_pm_above(const HvLds &S, int y, int x)        { return y > 0 ? S.wr_rec.mode[(y >> 2) - 1][x >> 2] : 1; }
-/* one coding unit of size n at CTU-relative (y, x)  [ref putCU_* :1272-1340] */
-static HD void hv_wr_cu(HvLds &S, HvWr &w, int L, int y, int x, int n, int info) {
-    const int i4 = y >> 2, j4 = x >> 2;
-    const int nxn = (info & HEVCE_INFO_NXN) != 0, split = (info & HEVCE_INFO_TUSPLIT) != 0;
-    const int lg = n == 8 ? 3 : n == 16 ? 4 : 5;
-    int modes[4], left[4], above[4];
-    modes[0] = S.wr_rec.mode[i4][j4]; left[0] = hv_wr_pm_left(S, L, y, x); above[0] = hv_wr_pm_above(S, y, x);
-    if (nxn) {
-        for (int s = 1; s < 4; s++) modes[s] = S.wr_rec.mode[i4 + (s >> 1)][j4 + (s & 1)];
-        left[1] = modes[0];                       above[1] = hv_wr_pm_above(S, y, x + 4);
-        left[2] = hv_wr_pm_left(S, L, y + 4, x);  above[2] = modes[0];
-        left[3] = modes[2];                       above[3] = modes[1];
-    }
-    if (n == 8) hv_wr_bin(S, w, CX_PART, !nxn);
-    const int parts = nxn ? 4 : 1;
-    int hit[4], rem[4];
-    for (int i = 0; i < parts; i++) {                            /* [ref :958-1018] */
-        int p[3];
-        hv_mpm(left[i], above[i], p);
-        const int md = modes[i];
-        hit[i] = (p[2] == md) ? 2 : (p[1] == md) ? 1 : (p[0] == md) ? 0 : -1;
-        const int hi = hv_max(p[0], hv_max(p[1], p[2])), lo = hv_min(p[0], hv_min(p[1], p[2])), mid = p[0] + p[1] + p[2] - hi - lo;
-        int r = md;
-        r -= (r > hi); r -= (r > mid); r -= (r > lo);
-        rem[i] = r;
-        hv_wr_bin(S, w, CX_YPM, hit[i] >= 0);
-    }
-    for (int i = 0; i < parts; i++) {
-        if (hit[i] >= 0) { hv_wr_bypass(w, hit[i] > 0, 1); if (hit[i] > 0) hv_wr_bypass(w, hit[i] - 1, 1); }
-        else hv_wr_bypass(w, rem[i], 5);
-    }
-    hv_wr_bin(S, w, CX_UVPM, 0);
-    if (!nxn) hv_wr_bin(S, w, CX_SPLIT_TU + (5 - lg), split);
-    hv_wr_bin(S, w, CX_UVCBF, 0);
-    hv_wr_bin(S, w, CX_UVCBF, 0);
-    if (!nxn && !split) {
-        const int cbf = hv_wr_nonzero(S, y, x, n);
-        hv_wr_bin(S, w, CX_YCBF + 1, cbf);
-        if (cbf) hv_wr_residual(S, w, y, x, n, lg, modes[0]);
-    } else {
-        const int h = n >> 1;
-        for (int s = 0; s < 4; s++) {
-            const int sy = y + (s >> 1) * h, sx = x + (s & 1) * h;
-            const int cbf = hv_wr_nonzero(S, sy, sx, h);
-            hv_wr_bin(S, w, CX_YCBF, cbf);
-            if (cbf) hv_wr_residual(S, w, sy, sx, h, lg - 1, modes[nxn ? s : 0]);
-        }
-    }
-}
 /* the writer starts on CTU `cw`: stage its record and its neighbours' CU sizes / modes in LDS.  Whole wavefront.
    The records were stored by this workgroup (barriers since); agent-scope loads so that no stale line of a record
    that was rewritten (a CTU analysed twice) can be picked up. */
@@ -2341,28 +2180,140 @@ static HD void hv_wr_stage(HvLds &S, const HevceImageDesc &im, int cw) {
         for (int k = 0; k < 4; k++) S.wr_ainfo[(lane - 8) * 4 + k] = (u8)(wi >> (8 * k));
     }
 }
-/* slice r of CTU cw: the split flags and the CU that start at 8x8 position r (z-order); after the last slice the
-   end_of_slice_segment_flag, the coder registers of the CTU and -- last CTU -- the coder's tail.  One lane. */
-static HDN void hv_wr_slice(const HevceImageDesc &im, int cw, int r) {
+/* Binarisation of the WHOLE CTU in one lane-parallel pass (the tokenisers of the trial encodes, exact tokens): lane = 4x4
+   position in z-order.  A transform block covers a contiguous, aligned range of z-positions; its groups sit in that range in
+   CODING order (lane base + i codes scan group ncg^2 - 1 - i), so that "coded earlier in the same block" is "lower lane" and
+   the greater1 carry is two ballots away, as in hv_bin_group.  Three token slots per z-position in the picture's writer area
+   (im.wr_tok): CU header (with the split flags of the CUs that begin there), block header, coefficient group; the coder then
+   walks the positions in order.  Wavefront 4's own scratch tile holds the token ring, the scan-ordered levels and the counts. */
+struct HvWrTile { unsigned ring[1024]; short lev[64][16]; u8 cnt[3][64]; u8 nzgrid[64]; unsigned short last[64]; };
+static HDN void hv_wr_tokenise(const HevceImageDesc &im, int cw) {
     HvLds &S = HV_S;
-    const int ncx = im.W >> 5, nctu = ncx * (im.H >> 5);
+    HV_LDSP HvWrTile &W = *(HV_LDSP HvWrTile *)&S.ws[4];
+    const int lane = hv_tid() & 63, ncx = im.W >> 5;
     const int L = (cw % ncx) > 0, A = cw >= ncx;
+    /* z-order position -> 4x4 coordinates inside the CTU */
+    const int zy = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4), zx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4);
+    const int info = S.wr_rec.info[zy][zx], n = 8 << (info & HEVCE_INFO_LOG2_MASK), lg = 3 + (info & HEVCE_INFO_LOG2_MASK);
+    const int nxn = (info & HEVCE_INFO_NXN) != 0, split = (info & HEVCE_INFO_TUSPLIT) != 0;
+    const int tn = (nxn || split) ? n >> 1 : n, tlg = (nxn || split) ? lg - 1 : lg, ncg = tn >> 2, ncgt = ncg * ncg;
+    const int base = lane & ~(ncgt - 1), cubase = lane & ~(((n >> 2) * (n >> 2)) - 1);
+    const int by = ((base >> 1) & 1) | ((base >> 2) & 2) | ((base >> 3) & 4), bx = (base & 1) | ((base >> 1) & 2) | ((base >> 2) & 4);   /* block origin */
+    const int cy = ((cubase >> 1) & 1) | ((cubase >> 2) & 2) | ((cubase >> 3) & 4), cx4 = (cubase & 1) | ((cubase >> 1) & 2) | ((cubase >> 2) & 4);
+    const int mode = S.wr_rec.mode[nxn ? by : cy][nxn ? bx : cx4];
+    const int kind = hv_scan_kind(tn, mode);
+    const int cg = ncgt - 1 - (lane - base);
+    int gy, gx;
+    hv_scan_cg(S, tlg, kind, cg, gy, gx);
+    /* the group's levels in scan order; which groups of the CTU hold one */
+    unsigned nzm = 0;
+    {
+        const HV_LDSP short *lev = (const HV_LDSP short *)&S.wr_rec.lev[0][0];
+#pragma unroll
+        for (int ii = 0; ii < 16; ii++) {
+            int iy, ix;
+            hv_scan_in(S, kind, ii, iy, ix);
+            const int v = lev[((by + gy) * 4 + iy) * 32 + (bx + gx) * 4 + ix];
+            W.lev[lane][ii] = (short)v;
+            nzm |= (unsigned)(v != 0) << ii;
+        }
+    }
+    W.nzgrid[(by + gy) * 8 + bx + gx] = (u8)(nzm != 0);
+    const u64 bnz = hv_ballot(nzm != 0);                            /* coding order */
+    WAVE_SYNC();
+    const u64 grid = hv_ballot(W.nzgrid[lane] != 0);                /* raster order: bit y4 * 8 + x4 */
+    const u64 mine = (bnz >> base) & (ncgt == 64 ? ~(u64)0 : (((u64)1 << ncgt) - 1));
+    const int cbf = mine != 0;
+    const int first = mine ? 63 - hv_clzll(mine & (~mine + 1)) : 0;   /* the block's first coded group = lowest lane with a level */
+    const int cg_last = ncgt - 1 - first;
+    if (cbf && lane == base + first) W.last[base] = (unsigned short)((cg_last << 4) | (31 - hv_clz(nzm)));
+    WAVE_SYNC();
+    const int last = cbf ? W.last[base] : 0;
+    const u64 cgsig = grid >> (by * 8 + bx);                        /* bit gy * 8 + gx relative to the block; hv_cg_load bounds its look-ups */
+    HV_GLOBAL u16 *slots = (HV_GLOBAL u16 *)im.wr_tok;
+    /* ---- coefficient groups ---- */
+    {
+        HvCg g;
+        hv_cg_load(S, g, (const HV_LDSP short *)W.lev[lane], tn, tlg, kind, cg, last, cgsig, cbf);
+        const u64 bg1 = hv_ballot(g.g1own);
+        const u64 before = bnz & ((((u64)1 << (lane - base)) - 1) << base);
+        const int g1 = before ? (int)((bg1 >> (63 - hv_clzll(before))) & 1) : 0;
+        int ch = 0;
+        if (cbf && cg <= cg_last) {
+            HvTokRingT<false> w = hv_tok_ring<false>(S, slots + (size_t)(2 * 64 + lane) * HV_SLOT);
+            ch = hv_cg_emit(S, w, g, g1);
+        }
+        W.cnt[2][lane] = (u8)ch;
+    }
+    /* ---- block headers: cbf_luma + last position  [ref :1038-1087] ---- */
+    {
+        int ch = 0;
+        if (lane == base) {
+            HvTokRingT<false> w = hv_tok_ring<false>(S, slots + (size_t)(64 + lane) * HV_SLOT);
+            ch = hv_tokenize_tu(S, w, tn, tlg, kind, 1, (nxn || split) ? CX_YCBF : CX_YCBF + 1, cbf, last);
+        }
+        W.cnt[1][lane] = (u8)ch;
+    }
+    /* ---- CU headers, preceded by the split_cu_flags of the 32x32 / 16x16 CUs that begin here and are split  [ref :943-1033, 1403-1404] ---- */
+    {
+        int ch = 0;
+        if (lane == cubase) {
+            const int y = cy * 4, x = cx4 * 4;
+            HvTokRingT<false> w = hv_tok_ring<false>(S, slots + (size_t)lane * HV_SLOT);
+            const int inc32 = (32 > hv_wr_cu_left(S, L, 0, 0)) + (32 > hv_wr_cu_above(S, A, 0, 0));
+            hv_emit(w, HV_CT(CX_SPLIT_CU + inc32, 1), lane == 0 && n < 32);
+            const int inc16 = (16 > hv_wr_cu_left(S, L, y & ~15, x & ~15)) + (16 > hv_wr_cu_above(S, A, y & ~15, x & ~15));
+            hv_emit(w, HV_CT(CX_SPLIT_CU + inc16, 1), (lane & 15) == 0 && n < 16);
+            HvModes pm;
+            for (int s4 = 0; s4 < 4; s4++) { pm.mode[s4] = 0; pm.left[s4] = 0; pm.above[s4] = 0; }
+            pm.mode[0] = S.wr_rec.mode[cy][cx4]; pm.left[0] = hv_wr_pm_left(S, L, y, x); pm.above[0] = hv_wr_pm_above(S, y, x);
+            if (nxn) {
+                for (int s4 = 1; s4 < 4; s4++) pm.mode[s4] = S.wr_rec.mode[cy + (s4 >> 1)][cx4 + (s4 & 1)];
+                pm.left[1] = pm.mode[0];                      pm.above[1] = hv_wr_pm_above(S, y, x + 4);
+                pm.left[2] = hv_wr_pm_left(S, L, y + 4, x);   pm.above[2] = pm.mode[0];
+                pm.left[3] = pm.mode[2];                      pm.above[3] = pm.mode[1];
+            }
+            const int inc = (n > hv_wr_cu_left(S, L, y, x)) + (n > hv_wr_cu_above(S, A, y, x));
+            ch = hv_tokenize_cu(w, n, lg, nxn ? 2 : (split ? 1 : 0), inc, pm);
+        }
+        W.cnt[0][lane] = (u8)ch;
+    }
+    WAVE_SYNC();
+    if (lane == 0) {
+        int total = 0;
+        for (int i = 0; i < 64; i++) total += W.cnt[0][i] + W.cnt[1][i] + W.cnt[2][i];
+        S.wst.pos = 0; S.wst.ci = 0; S.wst.done = 0; S.wst.total = total; S.wst.budget = (total + 14) / 15;
+    }
+}
+/* The writer's coder: `budget` chunks of CTU cw's tokens, in coding order, through the exact byte-emitting coder; after the
+   last one the end_of_slice_segment_flag, the coder registers of the CTU and -- last CTU of the picture -- the coder's tail.
+   One lane: bypass chunks and context-coded bins take different paths, a byte is only dealt with when there is one. */
+static HDN void hv_wr_engine(const HevceImageDesc &im, int cw, int budget) {
+    HvLds &S = HV_S;
+    HvLds::WrSt &T = S.wst;
+    if (T.done) return;
+    HV_LDSP HvWrTile &W = *(HV_LDSP HvWrTile *)&S.ws[4];
+    const int ncx = im.W >> 5, nctu = ncx * (im.H >> 5);
     HvWr w = hv_wr_load(S, im);
-    const int k16 = r >> 2, m = r & 3;
-    const int y16 = (k16 >> 1) * 16, x16 = (k16 & 1) * 16, y8 = y16 + (m >> 1) * 8, x8 = x16 + (m & 1) * 8;
-    const int info = S.wr_rec.info[y8 >> 2][x8 >> 2], size = 8 << (info & HEVCE_INFO_LOG2_MASK);
-    if (r == 0) {                                                                                           /* [ref :943-947, 1403-1404] */
-        const int inc = (32 > hv_wr_cu_left(S, L, 0, 0)) + (32 > hv_wr_cu_above(S, A, 0, 0));
-        hv_wr_bin(S, w, CX_SPLIT_CU + inc, size < 32);
-        if (size == 32) hv_wr_cu(S, w, L, 0, 0, 32, info);
+    u8 *cx = &S.nxn_ctx[0][HV_TL - 1];                              /* the writer's contexts: a column like a candidate's */
+    const HV_GLOBAL u16 *slots = (const HV_GLOBAL u16 *)im.wr_tok;
+    int pos = T.pos, ci = T.ci;
+    while (pos < 192 && budget > 0) {
+        const int z = pos / 3, kindslot = pos - 3 * z, nch = W.cnt[kindslot][z];
+        if (ci >= nch) { pos++; ci = 0; continue; }
+        const HvChunk ch = *((const HV_GLOBAL HvChunk *)(slots + (size_t)(kindslot * 64 + z) * HV_SLOT + HV_SLOT_TOK0) + ci);
+        HV_NOUNROLL for (int j = 0; j < 8; j++) {
+            const int tok = hv_chunk_get(ch, j);
+            if (tok & HV_TOK_BYP) {
+                const int nb = (tok >> 8) & 15;
+                if (nb) { w.low = (w.low << nb) + (unsigned)w.range * (unsigned)(tok & 0xff); w.nbits -= nb; hv_wr_carry(w); }
+            } else hv_wr_bin(S, w, cx + (tok & 0x1fff), (tok >> 14) & 1);
+        }
+        ci++; budget--;
     }
-    if (size < 32 && m == 0) {
-        const int inc = (16 > hv_wr_cu_left(S, L, y16, x16)) + (16 > hv_wr_cu_above(S, A, y16, x16));
-        hv_wr_bin(S, w, CX_SPLIT_CU + inc, size < 16);
-        if (size == 16) hv_wr_cu(S, w, L, y16, x16, 16, info);
-    }
-    if (size == 8) hv_wr_cu(S, w, L, y8, x8, 8, info);
-    if (r == 15) {
+    T.pos = pos; T.ci = ci;
+    if (pos >= 192) {
+        T.done = 1;
         hv_wr_terminate(w, cw == nctu - 1);                                                                 /* [ref :1630] */
         if (im.ctu_state) {
             int32_t *st = im.ctu_state + (size_t)cw * 8;
@@ -2400,8 +2351,8 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         /* shares its SIMD with wavefront 0, so no jobs: one of its lanes writes the previous CTU's slice data instead (slice = this
            round's 8x8 position); the older wavefront 0 wins the SIMD's issue arbitration */
         if (wr_on) {
-            if (k16 == 0 && m == 0) { hv_wr_stage(S, im, ctu - 1); WAVE_SYNC(); }
-            if (lane == 0) hv_wr_slice(im, ctu - 1, k16 * 4 + m);
+            if (k16 == 0 && m == 0) { hv_wr_stage(S, im, ctu - 1); WAVE_SYNC(); hv_wr_tokenise(im, ctu - 1); WAVE_SYNC(); }
+            if (lane == 0) hv_wr_engine(im, ctu - 1, (k16 * 4 + m) == 15 ? 100000 : S.wst.budget);
         }
         return;
     }
@@ -2557,7 +2508,7 @@ static HD void hv_init_tables(HvLds &S, int q, int tid) {
         int st = ((((iv >> 4) * 5 - 45) * qp) >> 4) + ((iv & 15) << 3) - 16;
         st = hv_min(hv_max(st, 1), 126);
         const u8 v = (u8)(st >= 64 ? (((st - 64) << 1) | 1) : ((63 - st) << 1));
-        S.ctx_fresh[i] = v; S.com_ctx[i] = (i == HV_CT_PAD) ? (u8)HV_PADCV : v; S.wr_ctx[i] = v;
+        S.ctx_fresh[i] = v; S.com_ctx[i] = (i == HV_CT_PAD) ? (u8)HV_PADCV : v; S.nxn_ctx[i][HV_TL - 1] = v;
     }
     if (tid == 300) { S.com.range = 510; S.com.low = 0; S.com.nbits = 23; S.com.nbytes = 0; S.com.bufbyte = 0xff; S.com.zeros = 0; S.com.nout = 0; S.com.pad = 0; S.wr = S.com; S.wr_epb = 0; }
 }
@@ -2606,7 +2557,9 @@ static HD void hv_wr_whole(HvLds &S, const HevceImageDesc &im, int cw) {
     if ((hv_tid() >> 6) == 4) {
         hv_wr_stage(S, im, cw);
         WAVE_SYNC();
-        if (hv_tid() == 4 * 64) for (int r = 0; r < 16; r++) hv_wr_slice(im, cw, r);
+        hv_wr_tokenise(im, cw);
+        WAVE_SYNC();
+        if (hv_tid() == 4 * 64) hv_wr_engine(im, cw, 100000);
     }
 }
 /* CTU `ctu` starts from here (the committed coder and contexts, what it reads of its left neighbour and of the CTU row above) */
@@ -2659,7 +2612,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
         const int wr_on = im.payload && ctu > 0 && hv_uni(S.wr_done) < ctu;   /* the writer does CTU ctu - 1 during this round */
         const int y0 = (ctu / ncx) * 32, x0 = (ctu % ncx) * 32;
         if (wr_on && tid == 4 * 64) { S.wsnap = S.wr; S.wr_epb = 0; }
-        if (wr_on && (tid >> 6) == 4) for (int i = tid & 63; i < HEVCE_NCTXP; i += 64) S.wsnap_ctx[i] = S.wr_ctx[i];
+        if (wr_on && (tid >> 6) == 4) for (int i = tid & 63; i < HEVCE_NCTXP; i += 64) S.wsnap_ctx[i] = S.nxn_ctx[i][HV_TL - 1];
         if (tail) { if (wr_on) hv_wr_whole(S, im, ctu - 1); }
         else {
             HevceRecord *rec = (HevceRecord *)(im.records + (size_t)ctu * HEVCE_REC_BYTES);
@@ -2763,7 +2716,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
             if (p_wr) {
                 ctu--;
                 if (tid == 0) S.wr = S.wsnap;
-                if (tid < HEVCE_NCTXP) S.wr_ctx[tid] = S.wsnap_ctx[tid];
+                if (tid < HEVCE_NCTXP) S.nxn_ctx[tid][HV_TL - 1] = S.wsnap_ctx[tid];
             } else if (wr_on && tid == 0) S.wr_done = ctu;
             BLOCK_SYNC();
             hv_snap_restore(S, ctu, (ctu % ncx) * 32, tid);

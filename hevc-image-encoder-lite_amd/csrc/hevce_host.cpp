@@ -53,7 +53,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 struct Image {
     int h0, w0, H, W, q, nctu;
     size_t off_img, off_rcon, off_rec, off_state, off_scratch;   /* into the device slab */
-    size_t off_payload, off_plen, off_stats;                     /* the kernel's stream writer: slice data, its length; re-analysis statistics */
+    size_t off_payload, off_plen, off_stats, off_wrtok;                     /* the kernel's stream writer: slice data, its length; re-analysis statistics */
     size_t hoff_rec, hoff_state, hoff_plen;                      /* into the pinned host slab */
     const void *ext_img = nullptr;
     long ext_stride = 0;                                         /* row stride of ext_img (0: w0) */
@@ -112,6 +112,7 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
         m.off_payload = d; d = align256(d + size_t(m.nctu) * 3200 + 64);
         m.off_plen = d;    d = align256(d + 4);
         m.off_stats = d;   d = align256(d + 8);
+        m.off_wrtok = d;   d = align256(d + HEVCE_WRTOK_BYTES);
         m.hoff_rec = h;    h = align256(h + size_t(m.nctu) * HEVCE_REC_BYTES);
         m.hoff_state = h;  h = align256(h + size_t(m.nctu) * 32);
         m.hoff_plen = h;   h = align256(h + 4);
@@ -225,6 +226,7 @@ int hevce_job_launch(hevce_job *j) {
             d.trace = j->h_trace ? j->h_trace + 1024 * i : nullptr;
             d.payload = j->device_emit ? j->d_slab + m.off_payload : nullptr;
             d.stats = (int32_t *)(j->d_slab + m.off_stats);
+            d.wr_tok = j->d_slab + m.off_wrtok;
             d.flags = j->flags; d.pad_ = 0;
             d.payload_len = j->device_emit ? (int32_t *)(j->d_slab + m.off_plen) : nullptr;
         }

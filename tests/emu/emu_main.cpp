@@ -72,6 +72,8 @@ int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, 
     im.dump = dump;
     if (payload) { im.payload = payload; im.payload_len = payload_len; }     /* the kernel's stream writer on */
     im.flags = flags; im.stats = stats;
+    std::vector<uint8_t> wrtok(HEVCE_WRTOK_BYTES, 0xEF);
+    im.wr_tok = wrtok.data();
     im.src_h = src_h; im.src_w = src_w; im.src_stride = src_w; im.qpd6 = q;
     im.H = ((src_h < HEVCE_MAXDIM ? src_h : HEVCE_MAXDIM) + 31) / 32 * 32;
     im.W = ((src_w < HEVCE_MAXDIM ? src_w : HEVCE_MAXDIM) + 31) / 32 * 32;

@@ -1,28 +1,64 @@
 #!/usr/bin/env python3
-"""Per-phase cycle profile (HEVCE_PROF build): shares of TU jobs / trial-context init / trial encodes / arg-min / commit."""
+"""In-kernel cycle probes (probe builds of the library: `make -C hevc-image-encoder-lite_amd/csrc prof prof2 wait bin jdur-N tu-N`).
+
+  gpu_prof.py phases [h w]   per-phase cycles per CU size                          (libhevce_prof.so,  -DHEVCE_PROF)
+  gpu_prof.py nxn            inside the NxN chain's 4x4 stages                     (libhevce_prof2.so, + -DHEVCE_PROF_NXN)
+  gpu_prof.py wait           wavefront 0's wait at the barrier closing each round  (libhevce_wait.so,  + -DHEVCE_PROF_WAIT)
+  gpu_prof.py bin            binarisation passes per CU level                      (libhevce_bin.so,   + -DHEVCE_PROF_BIN)
+  gpu_prof.py jdur N         length of wavefront N's jobs phase per round          (libhevce_jdurN.so, + -DHEVCE_PROF_JDUR=N)
+  gpu_prof.py tu N           phases of the N x N block job                         (libhevce_tuN.so,   + -DHEVCE_PROF_TU=N)
+Workload: 256x128 G2-16 (32 CTUs), qpd6 = 2, unless h w are given.  Set HEVCE_FLAGS=1 to probe the EXACT engines."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("HEVCE_LIB", os.path.join(ROOT, "hevc-image-encoder-lite_amd", "lib", "libhevce_prof.so"))
+kind = sys.argv[1] if len(sys.argv) > 1 else "phases"
+arg = sys.argv[2] if len(sys.argv) > 2 and kind in ("jdur", "tu") else ""
+libname = {"phases": "prof", "nxn": "prof2", "wait": "wait", "bin": "bin", "jdur": "jdur" + arg, "tu": "tu" + arg}[kind]
+os.environ.setdefault("HEVCE_LIB", os.path.join(ROOT, "hevc-image-encoder-lite_amd", "lib", f"libhevce_{libname}.so"))
 os.environ["HEVCE_TRACE"] = "1"
 import numpy as np
 import hevce_pkg, hevce_workload as wl
 hevce = hevce_pkg.load()
-h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (128, 256)
+h, w = (int(sys.argv[2]), int(sys.argv[3])) if kind == "phases" and len(sys.argv) > 3 else (128, 256)
 img = wl.gen_g2(h, w, 16)
 with hevce.Job([img.shape], 2) as job:
     job.upload(0, img); job.run()
-    tr = job.trace(0); tm = job.timings()
-prof = tr[:48].view(np.uint64).reshape(3, 8)
+    tr = job.trace(0); tm = job.timings(); st = job.stats(0)
 nctu = (hevce.pad32(h) // 32) * (hevce.pad32(w) // 32)
-tot = prof.sum()
+prof = tr[:48].view(np.uint64).reshape(3, 8)
+p2 = tr[48:112].view(np.uint64).astype(float)
 whole = int(tr[112:114].view(np.uint64)[0])
-print(f"{w}x{h}: kernel {tm['kernel_ms']:.1f} ms, {tm['kernel_ms']*1e3/nctu:.0f} us/CTU, WHOLE KERNEL {whole/nctu/1e3:.0f} k cycles/CTU (clock {whole/tm['kernel_ms']/1e6:.2f} GHz), stamped {tot/nctu/1e3:.0f} k/CTU")
-names = ["TU jobs", "ctx init", "engine", "arg-min", "commit", "binarise"]
-p2 = tr[48:80].view(np.uint64)
-for lvl, nm in enumerate(("8x8", "16x16", "32x32")):
-    print(f"  {nm} binarise/link:", "  ".join(f"{k} {100.0*p2[4+4*lvl+i]/tot:5.1f}%" for i, k in enumerate(("ctx+groups", "headers", "offsets", "copy"))))
-print(f"  engine phases {100.0*prof[0,6]/tot:5.1f}%")
-print("  NxN job:", "  ".join(f"{nm} {100.0*p2[i]/tot:5.1f}%" for i, nm in enumerate(("tu jobs", "tokenise", "engine", "select"))))
-for lvl, nm in enumerate(("8x8", "16x16", "32x32")):
-    print(f"  CU {nm:6s}", "  ".join(f"{names[p]} {100.0*prof[lvl,p]/tot:5.1f}%" for p in range(6)))
+print(f"{w}x{h}: kernel {tm['kernel_ms']:.1f} ms, {tm['kernel_ms']*1e3/nctu:.0f} us/CTU, WHOLE KERNEL {whole/nctu/1e3:.0f} k cycles/CTU "
+      f"(clock {whole/tm['kernel_ms']/1e6:.2f} GHz), CTUs analysed twice {st[0]}, coder mismatches {st[1]}")
+if kind == "phases":
+    tot = prof.sum()
+    print(f"  stamped {tot/nctu/1e3:.0f} k/CTU; per 8x8 round: jobs phase {prof[0,0]/nctu/16/1e3:.1f} k, engine phase {prof[0,6]/nctu/16/1e3:.1f} k, "
+          f"decide {(prof[0,2]+prof[0,3]+prof[0,4])/nctu/16/1e3:.1f} k")
+    names = ["jobs", "-", "split+finish", "arg-min", "commit", "ctx init", "engines", "-"]
+    for lvl, nm in enumerate(("8x8", "16x16", "32x32")):
+        print(f"  CU {nm:6s}", "  ".join(f"{names[p]} {100.0*prof[lvl,p]/tot:5.1f}%" for p in range(7) if names[p] != "-"))
+    print("  NxN chain:", "  ".join(f"{nm} {100.0*p2[i]/tot:5.1f}%" for i, nm in enumerate(("4x4 pipelines", "tokenise", "engine", "select", "tail"))))
+elif kind == "nxn":
+    stages = nctu * 64
+    print("per 4x4 stage (k cycles): border+sync+tu4 %.1f, tokenise %.1f, engine %.1f, select %.1f; tail per round %.1f" %
+          (tuple(p2[i] / stages / 1e3 for i in range(4)) + (p2[4] / nctu / 16 / 1e3,)))
+    for nm, v in zip(("predict", "residual+fwd+quant", "levels/dequant", "inverse+recon"), p2[16:20]): print(f"  tu4 {nm:20s} {v/stages/1e3:6.2f} k")
+elif kind == "wait":
+    print("NxN job per round (k cycles): stages %.1f, tail %.1f" % (p2[0:4].sum() / nctu / 16 / 1e3, p2[4] / nctu / 16 / 1e3))
+    print("wait of wavefront 0 at the jobs-phase barrier, k cycles per round:")
+    for k in range(4): print("  k16=%d: " % k + "  ".join("m=%d %6.1f" % (m, p2[16 + 4 * k + m] / nctu / 1e3) for m in range(4)))
+    print("  total per CTU: %.0f k" % (p2[16:32].sum() / nctu / 1e3))
+elif kind == "jdur":
+    print(f"jobs phase of wavefront {arg}, k cycles per round:")
+    for k in range(4): print("  k16=%d: " % k + "  ".join("m=%d %6.1f" % (m, p2[16 + 4 * k + m] / nctu / 1e3) for m in range(4)))
+    print("  total per CTU: %.0f k" % (p2[16:32].sum() / nctu / 1e3))
+elif kind == "bin":
+    for lvl, (nm, calls) in enumerate((("8x8  (16 calls, 16 candidates)", 16), ("16x16 (4 calls, 12 candidates)", 4), ("32x32 (1 call, 12 candidates)", 1))):
+        v = p2[16 + 4 * lvl:20 + 4 * lvl] / nctu / calls / 1e3
+        print(f"{nm:32s} k cycles per call: groups {v[0]:7.1f}  TU headers {v[1]:6.1f}  CU headers {v[2]:6.1f}  slot lists {v[3]:6.1f}")
+elif kind == "tu":
+    N = int(arg)
+    v6 = p2[16:22]
+    calls = {32: 18, 16: 36 + 9 * 4, 8: 80 + 20 * 4}[N] * nctu
+    print(f"hv_tu_job<{N}>: {v6.sum()/calls/1e3:.1f} k cycles per call")
+    for nm, v in zip(("refs", "predict", "fwd cols", "fwd rows+quant", "inv cols", "inv rows+recon"), v6): print(f"  {nm:16s} {v/calls/1e3:7.1f} k  {100*v/v6.sum():5.1f}%")
