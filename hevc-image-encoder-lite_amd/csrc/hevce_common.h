@@ -58,6 +58,7 @@ typedef struct HevceImageDesc {
     uint8_t       *records;   /* (H/32)*(W/32) HevceRecord, raster CTU order */
     int32_t       *ctu_state; /* optional: 8 ints per CTU (coder registers after the CTU) */
     uint8_t       *scratch;   /* HEVCE_SCRATCH_BYTES of per-image trial scratch */
+    const uint16_t *qlut;     /* 4 x 32768 levels: the quantiser's decision per coefficient magnitude, tables for 4x4 .. 32x32 at this qpd6 (hevce_quant.h) */
     int32_t src_h, src_w, H, W, qpd6, status;
     int64_t src_stride;
     int32_t       *dump;      /* diagnostics: per CU evaluation, 72 x (sse, cost) ints (NULL = off) */

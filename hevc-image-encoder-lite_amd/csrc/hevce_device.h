@@ -30,6 +30,12 @@ static inline unsigned hv_perm(unsigned a, unsigned b, unsigned sel) {
     return r;
 }
 static inline void hv_atomic_add(int *p, int v) { *p += v; }
+struct HvLaneTab { int a[64]; };                            /* emulation: the one fiber that runs wave-uniform code owns all 64 entries */
+#define HV_LT_LOAD(tab, L, expr) do { for (int L = 0; L < 64; L++) (tab).a[L] = (expr); } while (0)
+#define HV_LT_EACH(tab, L, VAL, stmt) do { for (int L = 0; L < 64; L++) { const int VAL = (tab).a[L]; stmt; } } while (0)
+static inline int  hv_lt_get(const HvLaneTab &t, int i) { return t.a[i]; }
+static inline void hv_lt_put(HvLaneTab &t, int i, int val) { t.a[i] = val; }
+template <typename T> static inline T *hv_uni_ptr(T *p) { return p; }
 #else
 #include <hip/hip_runtime.h>
 #define HD  __device__ __forceinline__
@@ -73,6 +79,17 @@ static HD unsigned long long hv_ballot(int p) { return __ballot(p); }   /* one b
 static HD int  hv_clzll(unsigned long long v) { return __clzll((long long)v); }
 static HD unsigned hv_perm(unsigned a, unsigned b, unsigned sel) { return __builtin_amdgcn_perm(a, b, sel); }   /* v_perm_b32: result byte i = byte sel.byte[i] of {a:7..4, b:3..0} */
 static HD void hv_atomic_add(int *p, int v) { atomicAdd(p, v); }
+/* a 64-entry table with entry i in lane i of one VGPR: read / written with a wave-uniform index by v_readlane / v_writelane,
+   i.e. without any memory access, and the result is wave-uniform (scalar arithmetic from there on) */
+struct HvLaneTab { int v; };
+#define HV_LT_LOAD(tab, L, expr) do { const int L = hv_tid() & 63; (tab).v = (expr); } while (0)
+#define HV_LT_EACH(tab, L, VAL, stmt) do { const int L = hv_tid() & 63; const int VAL = (tab).v; stmt; } while (0)
+static HD int  hv_lt_get(const HvLaneTab &t, int i) { return __builtin_amdgcn_readlane(t.v, i); }
+static HD void hv_lt_put(HvLaneTab &t, int i, int val) { t.v = ((int)(threadIdx.x & 63) == i) ? val : t.v; }   /* a compare and a select (v_writelane takes one SGPR only) */
+template <typename T> static HD T *hv_uni_ptr(T *p) {
+    const unsigned long long a = (unsigned long long)p;
+    return (T *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a));
+}
 static HD unsigned hv_ldg_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   /* read at the L2: never a stale L1 line */
 #endif
 
@@ -161,7 +178,7 @@ DEVCONST u8 hv_sigpos[8]   = HEVCE_TAB_SIGPOS;
 /* --------------------------------------------------------------------------------------------- */
 struct HvTuInfo { u64 cgsig; int last; int cbf; };          /* per (trial, TU): 8x8 bitmap of non-zero 4x4 groups */
 
-struct HvWaveScr {                                          /* private to one wavefront */
+struct alignas(16) HvWaveScr {                              /* private to one wavefront */
     short scr[64 * 34];                                     /* [slot][row][N+2]: transposition buffer           */
     u8    pred[64 * 32];                                    /* [slot][row][N] prediction                        */
     u8    bord[672];                                        /* [slot][raw|smoothed][4N+4] reference samples     */
@@ -249,7 +266,8 @@ struct alignas(16) HvLds {
     unsigned long long prof2[32];                           /* HEVCE_PROF: inside the NxN job (tu jobs, tokenise, engine, select) */
 #endif
     int *trace;
-    HvWaveScr ws[HV_NWAVES];
+    const u16 *qlut;                                        /* the picture's four level tables (hv_qlut) */
+    alignas(16) HvWaveScr ws[HV_NWAVES];                    /* 16-byte rows are read / written as vectors */
 };
 
 typedef unsigned HvChunk __attribute__((vector_size(16), may_alias));   /* 16 bytes moved as one dwordx4: eight 16-bit tokens / records, packed levels, samples */
@@ -1008,61 +1026,20 @@ static HD void hv_fterminate(HvFCod &c, int bin) {
 }
 
 /* --------------------------------------------------------------------------------------------- */
-/* quantiser  [ref HEVCe.c:526-595]                                                                 */
+/* quantiser  [ref HEVCe.c:526-595]: the level of a coefficient is looked up                                                   */
 /* --------------------------------------------------------------------------------------------- */
-static HD int hv_level_rate(int lv) {                                                                      /* [ref :526-535] */
-    /* lv < 6: table {0, 70000, 90000, 92000, 157536, 190304}; else 92000 + ((4 + 2*prefix_len(lv-6)) << 15) -- selects only */
-    const int i = 31 - hv_clz((unsigned)hv_max(lv - 5, 1));
-    const int big = 92000 + ((4 + 2 * i) << 15);
-    int r = lv == 0 ? 0 : 70000;
-    r = lv >= 2 ? 90000 : r;
-    r = lv >= 3 ? 92000 : r;
-    r = lv >= 4 ? 157536 : r;
-    r = lv >= 5 ? 190304 : r;
-    return lv >= 6 ? big : r;
-}
-/* RD cost with the per-qpd6 weights already selected (wd, wb) and their overflow guards (I32MAX / w)  [ref :177-185] */
-struct HvRd { int wd, wb, gd, gb; };
-static HD HvRd hv_rd_make(int q) {
-    HvRd r;
-    r.wd = (q < 3) ? 11 : (q == 3 ? 5 : 1);
-    r.wb = (q == 0) ? 1 : (q == 1) ? 4 : (q == 2) ? 16 : (q == 3) ? 29 : 23;
-    r.gd = HV_I32MAX / r.wd; r.gb = HV_I32MAX / r.wb;
-    return r;
-}
-static HD int hv_rd(const HvRd &w, int dist, int bits) {
-    const int a = (w.gd <= dist) ? HV_I32MAX : w.wd * dist;
-    const int b = (w.gb <= bits) ? HV_I32MAX : w.wb * bits;
-    return (HV_I32MAX - a <= b) ? HV_I32MAX : a + b;
-}
-/* returns the level magnitude; d = scaled magnitude used by the group zero-out test.  Three candidates (level, level-1,
-   level-2, not below zero), strict '<' so the highest level wins ties  [ref :566-580]; straight-line code */
-static HD int hv_quant1(int q, int sh, int dsh, int av, int &d) {
-    const HvRd w = hv_rd_make(q);
-    const int half = 1 << sh >> 1, dmax = HV_I32MAX - half;
-    d = (av > 0x1ffff) ? dmax : hv_min((av & 0x1ffff) << 14, dmax);
-    const int lv0 = hv_clip16((d + half) >> sh);
-    int best = HV_I32MAX, pick = 0;
-    /* The third candidate can only win when the reference's saturating square is reached, i.e. for qpd6 = 4: with
-       E = 2^(sh - dsh) = 2^(11 + q) the scaled distances of candidates 1 and 2 are e1 in [E/2, 3E/2) and e2 = e1 + E, so their
-       distortions differ by at least (2 e1 E + E^2) / 128 >= E^2 / 64, weighted 11, 11, 11, 5 for q = 0..3: >= 7.2e5, 2.9e6,
-       1.15e7, 2.1e7 -- an order of magnitude above the largest rate step times its weight (70000 x 1, 4, 16, 29).  For
-       q = 4 both squares can saturate to the same value and the cheaper level wins. */
-    const int ncand = (q >= 4) ? 3 : 2;
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-        if (t >= ncand) break;
-        const int lv = hv_max(lv0 - t, 0);
-        const int e = hv_abs(d - (lv << sh)) >> dsh;
-        const int dist = ((e < 46340) ? (int)hv_umul24((unsigned)e, (unsigned)e) : HV_I32MAX) >> 7;   /* 46339^2 < 2^31 */
-        /* hv_rd() without its overflow guards: dist <= 2^24 - 1 and the level rate <= 1 140 576, so with wd <= 11 and
-           wb <= 29 neither product nor their sum can reach 2^31  [ref :177-185 saturates only beyond that] */
-        const int cst = (int)(hv_umul24((unsigned)w.wd, (unsigned)dist) + hv_umul24((unsigned)w.wb, (unsigned)hv_level_rate(lv)));   /* all operands < 2^24 */
-        const bool take = (lv0 - t >= 0) && (cst < best);
-        best = take ? cst : best;
-        pick = take ? lv : pick;
-    }
-    return pick;
+#include "hevce_quant.h"
+/* The reference tries level, level-1, level-2 and keeps the cheapest in w1 * distortion + w2 * rate  [ref :566-580]; for a
+   fixed qpd6 and transform size that choice depends on the coefficient's magnitude alone, so the host tabulates
+   hv_quant1() once (im.qlut: four tables of HEVCE_QLUT_N 16-bit levels for the picture's qpd6, 256 KB, L2-resident) and the
+   block jobs gather from it: one load per coefficient instead of ~100 VALU instructions.  |coefficient| <= 32640 for 8-bit
+   samples (the bound the 16-bit staging of the transforms already relies on); the index is clamped all the same.
+   d = the scaled magnitude for the group zero-out test  [ref :555, 585-589]. */
+typedef const HV_GLOBAL u16 *HvQlut;
+template <int LG> static HD HvQlut hv_qlut(const HvLds &S) { return (HvQlut)S.qlut + (LG - 2) * HEVCE_QLUT_N; }
+static HD int hv_quant_lut(HvQlut lut, int av, int &d) {
+    d = av << 14;
+    return lut[hv_min(av, HEVCE_QLUT_N - 1)];
 }
 
 /* --------------------------------------------------------------------------------------------- */
@@ -1308,17 +1285,24 @@ static HD HvTuOut hv_tu_job(int wave, int lane, int q,
     int last = -1, nzmask_lo = 0, nzmask_hi = 0;
     {
         constexpr int s2 = LG - 1 + 7;
-        const int sh = 21 - LG + q, dsh = 10 - LG, thr = 9 << sh >> 2, qsh = 7 - LG + q;
+        const int sh = 21 - LG + q, thr = 9 << sh >> 2, qsh = 7 - LG + q;
+        const HvQlut lut = hv_qlut<LG>(S);
 #pragma unroll
         for (int k = 0; k < N; k++) v[k] = scr[j * RS + k];
         const int *tab = HvTm<N>::f();
         if constexpr (N >= 8) {
             /* all N coefficients of the row at once; they wait in the row's own scratch line (16 bits: |coefficient| <= 32640
-               for 8-bit samples, the bound the first pass already relies on) until their 4x4 group's turn */
+               for 8-bit samples, the bound the first pass already relies on) until their 4x4 group's turn; their levels are
+               requested from the table right away (N gathers in flight), v[] keeps the magnitudes */
             int out[N];
             HvBfly<N, N>::fwd(v, out);
 #pragma unroll
-            for (int i = 0; i < N; i++) scr[j * RS + i] = (short)((out[i] + (1 << s2 >> 1)) >> s2);
+            for (int i = 0; i < N; i++) {
+                const int coef = (out[i] + (1 << s2 >> 1)) >> s2;
+                scr[j * RS + i] = (short)coef;
+                int d;
+                v[i] = hv_quant_lut(lut, hv_abs(coef), d);
+            }
         }
         for (int g = 0; g < N / 4; g++) {
             int lv[4], sum = 0;
@@ -1333,8 +1317,8 @@ static HD HvTuOut hv_tu_job(int wave, int lane, int q,
                     for (int k = 0; k < N; k++) acc += hv_mul24(tab[cidx * N + k], v[k]);
                     coef = acc >> s2;
                 }
-                int d;
-                const int mag = hv_quant1(q, sh, dsh, hv_abs(coef), d);
+                int d = hv_abs(coef) << 14, mag;
+                if constexpr (N >= 8) mag = v[cidx]; else mag = hv_quant_lut(lut, hv_abs(coef), d);
                 lv[e] = coef < 0 ? -mag : mag;
                 sum += hv_min(d, thr);
             }
@@ -1570,17 +1554,20 @@ static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int 
 #pragma unroll
         for (int j = 0; j < 4; j++) t[i * 4 + j] = (hv_mul24(D[i * 4], r[j]) + hv_mul24(D[i * 4 + 1], r[4 + j]) + hv_mul24(D[i * 4 + 2], r[8 + j]) + hv_mul24(D[i * 4 + 3], r[12 + j]) + 1) >> 1;   /* 24-bit multiplies throughout: |operands| < 2^16 x 2^7; a plain product becomes a shift-and-add chain or a quarter-rate 32-bit multiply */
     const int sh = 19 + q, thr = 9 << sh >> 2, qsh = 5 + q;
-    int lv[16], sum = 0;
+    const HvQlut lut = hv_qlut<2>(S);
+    int lv[16], cf[16], sum = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int coef = (hv_mul24(t[i * 4], D[j * 4]) + hv_mul24(t[i * 4 + 1], D[j * 4 + 1]) + hv_mul24(t[i * 4 + 2], D[j * 4 + 2]) + hv_mul24(t[i * 4 + 3], D[j * 4 + 3]) + 128) >> 8;
             int d;
-            const int mag = hv_quant1(q, sh, 8, hv_abs(coef), d);
-            lv[i * 4 + j] = coef < 0 ? -mag : mag;
+            cf[i * 4 + j] = coef;
+            lv[i * 4 + j] = hv_quant_lut(lut, hv_abs(coef), d);       /* sixteen gathers in flight */
             sum += hv_min(d, thr);
         }
+#pragma unroll
+    for (int k = 0; k < 16; k++) lv[k] = cf[k] < 0 ? -lv[k] : lv[k];
     HV_NXT(1);
     /* levels in scan order: the three 4x4 orders are compile-time permutations of the raster positions, picked per lane by
        selects (no table reads, no divergent paths); two 16-byte LDS stores instead of sixteen scattered ones */
@@ -2287,42 +2274,132 @@ static HDN void hv_wr_tokenise(const HevceImageDesc &im, int cw) {
 }
 /* The writer's coder: `budget` chunks of CTU cw's tokens, in coding order, through the exact byte-emitting coder; after the
    last one the end_of_slice_segment_flag, the coder registers of the CTU and -- last CTU of the picture -- the coder's tail.
-   One lane: bypass chunks and context-coded bins take different paths, a byte is only dealt with when there is one. */
-static HDN void hv_wr_engine(const HevceImageDesc &im, int cw, int budget) {
+   A serial program, so it is written as WAVE-UNIFORM code: the whole wavefront executes it, every value is a scalar (SGPRs, scalar
+   ALU: it does not compete with the NxN chain for the SIMD's vector issue), and what would be table look-ups in memory --
+   the 104 context bytes, the LPS ranges, the state transitions -- are lanes of four VGPRs read and written by v_readlane /
+   v_writelane: no memory latency anywhere in the bin loop except the token chunks, which are fetched one ahead. */
+struct HvWrS { int range; unsigned low; int nbits, pending, held, zeros, n, epb; };
+static HD void hv_wrs_put(HvWrS &w, HV_GLOBAL u8 *out, int byte, int lane0) {                            /* [ref :821-832] */
+    byte &= 0xff;
+    if (w.zeros >= 2 && byte <= 3) { if (lane0) out[w.n] = 3; w.n++; w.zeros = 0; w.epb++; }
+    if (lane0) out[w.n] = (u8)byte;
+    w.n++;
+    w.zeros = byte ? 0 : w.zeros + 1;
+}
+static HD void hv_wrs_carry(HvWrS &w, HV_GLOBAL u8 *out, int lane0) {                                    /* [ref :859-879] */
+    if (w.nbits >= 12) return;
+    const int lead = (int)(w.low >> (24 - w.nbits));
+    w.nbits += 8;
+    w.low &= 0xffffffffu >> w.nbits;
+    if (lead == 0xff) { w.pending++; return; }
+    if (w.pending > 0) {
+        const int c = lead >> 8, fill = (0xff + c) & 0xff;
+        hv_wrs_put(w, out, w.held + c, lane0);
+        w.held = lead & 0xff;
+        for (; w.pending > 1; w.pending--) hv_wrs_put(w, out, fill, lane0);
+    } else { w.pending = 1; w.held = lead; }                     /* first byte ever: stored unmasked, as the reference does */
+}
+static HDN void hv_wr_engine(const HevceImageDesc &im_, int cw, int budget) {
     HvLds &S = HV_S;
     HvLds::WrSt &T = S.wst;
-    if (T.done) return;
+    const int lane = hv_tid() & 63, lane0 = lane == 0;
+#ifdef HEVCE_EMU
+    if (lane) return;                                            /* emulation: one fiber runs the wave-uniform program */
+#endif
+    if (hv_uni(T.done)) return;
+    cw = hv_uni(cw); budget = hv_uni(budget);
+    const HevceImageDesc &im = *hv_uni_ptr(&im_);
     HV_LDSP HvWrTile &W = *(HV_LDSP HvWrTile *)&S.ws[4];
-    const int ncx = im.W >> 5, nctu = ncx * (im.H >> 5);
-    HvWr w = hv_wr_load(S, im);
-    u8 *cx = &S.nxn_ctx[0][HV_TL - 1];                              /* the writer's contexts: a column like a candidate's */
-    const HV_GLOBAL u16 *slots = (const HV_GLOBAL u16 *)im.wr_tok;
-    int pos = T.pos, ci = T.ci;
+    const int ncx = hv_uni(im.W) >> 5, nctu = ncx * (hv_uni(im.H) >> 5);
+    HV_GLOBAL u8 *out = (HV_GLOBAL u8 *)hv_uni_ptr(im.payload);
+    const HV_GLOBAL u16 *slots = (const HV_GLOBAL u16 *)hv_uni_ptr(im.wr_tok);
+    HvWrS w = { hv_uni(S.wr.range), (unsigned)hv_uni((int)S.wr.low), hv_uni(S.wr.nbits), hv_uni(S.wr.nbytes), hv_uni(S.wr.bufbyte),
+                hv_uni(S.wr.zeros), hv_uni(S.wr.nout), hv_uni(S.wr_epb) };
+    /* lane tables: contexts 0..63 / 64..103 (the writer's column of context bytes), LPS ranges and LPS transitions per state */
+    HvLaneTab cxa, cxb, tl4, tnx;
+    HV_LT_LOAD(cxa, l_, S.nxn_ctx[l_][HV_TL - 1]);
+    HV_LT_LOAD(cxb, l_, S.nxn_ctx[hv_min(64 + l_, HEVCE_NCTXP - 1)][HV_TL - 1]);
+    HV_LT_LOAD(tl4, l_, (int)S.lps4[l_]);
+    HV_LT_LOAD(tnx, l_, (int)S.lpsnext[l_]);
+    int pos = hv_uni(T.pos), ci = hv_uni(T.ci);
+    /* the chunk at (pos, ci), or the first one after it; pos = 192: none left */
+    #define HV_WR_SEEK() do { while (pos < 192) { const int z_ = pos / 3, k_ = pos - 3 * z_; if (ci < hv_uni((int)W.cnt[k_][z_])) break; pos++; ci = 0; } } while (0)
+    #define HV_WR_ADDR() ((const HV_GLOBAL HvChunk *)(slots + (size_t)((pos - 3 * (pos / 3)) * 64 + pos / 3) * HV_SLOT + HV_SLOT_TOK0) + ci)
+    HV_WR_SEEK();
+    HvChunk nxt = { 0, 0, 0, 0 };
+    if (pos < 192) nxt = *HV_WR_ADDR();
     while (pos < 192 && budget > 0) {
-        const int z = pos / 3, kindslot = pos - 3 * z, nch = W.cnt[kindslot][z];
-        if (ci >= nch) { pos++; ci = 0; continue; }
-        const HvChunk ch = *((const HV_GLOBAL HvChunk *)(slots + (size_t)(kindslot * 64 + z) * HV_SLOT + HV_SLOT_TOK0) + ci);
-        HV_NOUNROLL for (int j = 0; j < 8; j++) {
-            const int tok = hv_chunk_get(ch, j);
-            if (tok & HV_TOK_BYP) {
-                const int nb = (tok >> 8) & 15;
-                if (nb) { w.low = (w.low << nb) + (unsigned)w.range * (unsigned)(tok & 0xff); w.nbits -= nb; hv_wr_carry(w); }
-            } else hv_wr_bin(S, w, cx + (tok & 0x1fff), (tok >> 14) & 1);
-        }
+        unsigned c4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) c4[k] = (unsigned)hv_uni((int)nxt[k]);
         ci++; budget--;
+        HV_WR_SEEK();
+        if (pos < 192) nxt = *HV_WR_ADDR();                      /* the next chunk is on its way while this one is coded */
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int tok = (int)((c4[j >> 1] >> ((j & 1) << 4)) & 0xffffu);
+            if (tok & HV_TOK_BYP) {                                                                         /* [ref :899-911] */
+                const int nb = (tok >> 8) & 15;
+                if (nb) { w.low = (w.low << nb) + (unsigned)w.range * (unsigned)(tok & 0xff); w.nbits -= nb; hv_wrs_carry(w, out, lane0); }
+            } else {                                                                                        /* [ref :914-933] */
+                const int idx = ((tok & 0x1fff) * 911) >> 16;    /* the token holds idx * HV_TL (72); 911 / 65536 = 1 / 71.94: exact for idx < 1170 */
+                const int bin = (tok >> 14) & 1;
+                const int va = hv_lt_get(cxa, idx & 63), vb = hv_lt_get(cxb, idx & 63);
+                const int v = idx < 64 ? va : vb, st = v >> 1, mps = v & 1;
+                const unsigned l4 = (unsigned)hv_lt_get(tl4, st & 63);
+                const int lps = (int)((l4 >> (((w.range >> 6) & 3) << 3)) & 0xff);
+                const int rm = w.range - lps;
+                int nv;
+                if (bin != mps) {
+                    const int sh = hv_clz_nz((unsigned)lps) - 23;
+                    w.low = (w.low + (unsigned)rm) << sh;
+                    w.range = lps << sh;
+                    w.nbits -= sh;
+                    nv = st == 0 ? (mps ^ 1) : ((hv_lt_get(tnx, st & 63) << 1) | mps);
+                } else {
+                    nv = st < 62 ? v + 2 : v;
+                    if (rm < 256) { w.low <<= 1; w.range = rm << 1; w.nbits--; } else w.range = rm;
+                }
+                hv_lt_put(cxa, idx & 63, idx < 64 ? nv : va);
+                hv_lt_put(cxb, idx & 63, idx < 64 ? vb : nv);
+                hv_wrs_carry(w, out, lane0);
+            }
+        }
     }
-    T.pos = pos; T.ci = ci;
+    #undef HV_WR_SEEK
+    #undef HV_WR_ADDR
+    int done = 0;
     if (pos >= 192) {
-        T.done = 1;
-        hv_wr_terminate(w, cw == nctu - 1);                                                                 /* [ref :1630] */
-        if (im.ctu_state) {
-            int32_t *st = im.ctu_state + (size_t)cw * 8;
+        done = 1;
+        /* end_of_slice_segment_flag  [ref :882-896, 1630] */
+        w.range -= 2;
+        if (cw == nctu - 1) { w.low = (w.low + (unsigned)w.range) << 7; w.range = 256; w.nbits -= 7; }
+        else if (w.range < 256) { w.low <<= 1; w.range <<= 1; w.nbits--; }
+        hv_wrs_carry(w, out, lane0);
+        int32_t *st = hv_uni_ptr(im.ctu_state);
+        if (st && lane0) {
+            st += (size_t)cw * 8;
             st[0] = w.range; st[1] = (int32_t)w.low; st[2] = w.nbits; st[3] = w.pending; st[4] = w.held; st[5] = w.zeros;
             st[6] = w.n; st[7] = 8 * (w.n + w.pending) + 23 - w.nbits;
         }
-        if (cw == nctu - 1) { hv_wr_finish(w); if (im.payload_len) *im.payload_len = w.n; }               /* [ref :1640-1641] */
+        if (cw == nctu - 1) {                                                                               /* [ref :840-856, 1640-1641] */
+            int fill = 0;
+            if ((w.low >> (32 - w.nbits)) > 0) { hv_wrs_put(w, out, w.held + 1, lane0); w.low -= 1u << (32 - w.nbits); }
+            else { if (w.pending > 0) hv_wrs_put(w, out, w.held, lane0); fill = 0xff; }
+            for (; w.pending > 1; w.pending--) hv_wrs_put(w, out, fill, lane0);
+            const int tail = (int)((w.low >> 8) << w.nbits);
+            hv_wrs_put(w, out, tail >> 16, lane0); hv_wrs_put(w, out, tail >> 8, lane0); hv_wrs_put(w, out, tail, lane0);
+            int32_t *pl = hv_uni_ptr(im.payload_len);
+            if (pl && lane0) *pl = w.n;
+        }
     }
-    hv_wr_store(S, w);
+    HV_LT_EACH(cxa, l_, v_, S.nxn_ctx[l_][HV_TL - 1] = (u8)v_);
+    HV_LT_EACH(cxb, l_, v_, if (64 + l_ < HEVCE_NCTXP) S.nxn_ctx[64 + l_][HV_TL - 1] = (u8)v_);
+    if (lane0) {
+        T.pos = pos; T.ci = ci; T.done = done;
+        S.wr.range = w.range; S.wr.low = w.low; S.wr.nbits = w.nbits; S.wr.nbytes = w.pending; S.wr.bufbyte = w.held; S.wr.zeros = w.zeros; S.wr.nout = w.n; S.wr.pad = 0;
+        S.wr_epb = w.epb;
+    }
 }
 
 /* TU-job phase of the 8x8 CU number m (0..3) of the 16x16 CU number k16 (0..3).  Wavefront 0 walks the NxN chain, the
@@ -2352,7 +2429,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
            round's 8x8 position); the older wavefront 0 wins the SIMD's issue arbitration */
         if (wr_on) {
             if (k16 == 0 && m == 0) { hv_wr_stage(S, im, ctu - 1); WAVE_SYNC(); hv_wr_tokenise(im, ctu - 1); WAVE_SYNC(); }
-            if (lane == 0) hv_wr_engine(im, ctu - 1, (k16 * 4 + m) == 15 ? 100000 : S.wst.budget);
+            hv_wr_engine(im, ctu - 1, (k16 * 4 + m) == 15 ? 100000 : S.wst.budget);
         }
         return;
     }
@@ -2559,7 +2636,7 @@ static HD void hv_wr_whole(HvLds &S, const HevceImageDesc &im, int cw) {
         WAVE_SYNC();
         hv_wr_tokenise(im, cw);
         WAVE_SYNC();
-        if (hv_tid() == 4 * 64) hv_wr_engine(im, cw, 100000);
+        hv_wr_engine(im, cw, 100000);
     }
 }
 /* CTU `ctu` starts from here (the committed coder and contexts, what it reads of its left neighbour and of the CTU row above) */
@@ -2586,7 +2663,7 @@ static HD void hv_snap_restore(HvLds &S, int ctu, int x0, int tid) {
    writer would (each CTU once). */
 static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int tid = hv_tid(), q = im.qpd6, H = im.H, W = im.W;
-    if (tid == 0) S.trace = im.trace;
+    if (tid == 0) { S.trace = im.trace; S.qlut = im.qlut; }
 #ifdef HEVCE_ANYPROF
     if (tid < 24) (&S.prof[0][0])[tid] = 0;
     if (tid < 32) S.prof2[tid] = 0;

@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -26,9 +27,9 @@
 #include <vector>
 
 extern "C" int hevce_launch_test_tu(const unsigned char *org, const unsigned char *nbr, int n, int q, int aL, int aLB, int aA, int aAR,
-                                    short *lev, unsigned char *rec, int *info, hipStream_t stream);
+                                    short *lev, unsigned char *rec, int *info, const unsigned short *qlut, hipStream_t stream);
 extern "C" int hevce_launch_test_chain(const unsigned char *org, const unsigned char *nbr, int n, int q, int aL, int aLB, int aA, int aAR,
-                                       unsigned char *scratch, int *info, hipStream_t stream);
+                                       unsigned char *scratch, int *info, const unsigned short *qlut, hipStream_t stream);
 extern "C" int hevce_launch_analyse(const HevceImageDesc *d_images, int n, hipStream_t stream);   /* hevce_kernel.hip */
 
 namespace {
@@ -46,6 +47,47 @@ int fail(const char *fmt, ...) {
     return -1;
 }
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+/* ---- the quantiser's level tables (hevce_quant.h): 5 qpd6 x 4 transform sizes x 32768 magnitudes, built once per process
+   and uploaded once per device; the kernel gathers from the four tables of a picture's qpd6 ---- */
+namespace quant {
+#define HD inline
+#define HV_I32MAX 0x7fffffff
+inline int hv_min(int a, int b) { return a < b ? a : b; }
+inline int hv_max(int a, int b) { return a > b ? a : b; }
+inline int hv_abs(int a) { return a < 0 ? -a : a; }
+inline int hv_clip16(int v) { return hv_min(hv_max(v, -32768), 32767); }
+inline int hv_clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
+inline unsigned hv_umul24(unsigned a, unsigned b) { return a * b; }
+#include "hevce_quant.h"
+#undef HD
+#undef HV_I32MAX
+}  // namespace quant
+constexpr size_t kQlutPerQ = size_t(4) * HEVCE_QLUT_N;       /* entries per qpd6 */
+std::mutex g_qlut_mutex;
+uint16_t *g_qlut_dev[64] = {};                               /* per HIP device: 5 x kQlutPerQ entries */
+const uint16_t *qlut_host() {
+    static std::vector<uint16_t> tab;
+    if (tab.empty()) {
+        tab.resize(5 * kQlutPerQ);
+        for (int q = 0; q < 5; q++)
+            for (int t = 0; t < 4; t++)
+                for (int av = 0; av < HEVCE_QLUT_N; av++) tab[q * kQlutPerQ + size_t(t) * HEVCE_QLUT_N + av] = (uint16_t)quant::hv_qlut_entry(q, t, av);
+    }
+    return tab.data();
+}
+/* device pointer to the tables of qpd6 q on `device` (current device must be `device`); nullptr on failure */
+const uint16_t *qlut_device(int device, int q) {
+    std::lock_guard<std::mutex> lock(g_qlut_mutex);
+    if (device < 0 || device >= 64) return nullptr;
+    if (!g_qlut_dev[device]) {
+        uint16_t *d = nullptr;
+        if (hipMalloc((void **)&d, 5 * kQlutPerQ * 2) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, qlut_host(), 5 * kQlutPerQ * 2, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        g_qlut_dev[device] = d;
+    }
+    return g_qlut_dev[device] + size_t(q) * kQlutPerQ;
+}
 
 inline int pad32(int v) { return ((v < HEVCE_MAXDIM ? v : HEVCE_MAXDIM) + 31) / 32 * 32; }
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
@@ -222,6 +264,8 @@ int hevce_job_launch(hevce_job *j) {
             d.records = j->d_slab + m.off_rec;
             d.ctu_state = (int32_t *)(j->d_slab + m.off_state);
             d.scratch = j->d_slab + m.off_scratch;
+            d.qlut = qlut_device(j->device, m.q);
+            if (!d.qlut) return fail("the quantiser tables could not be placed on device %d", j->device);
             d.src_h = m.h0; d.src_w = m.w0; d.src_stride = (m.ext_img && m.ext_stride) ? m.ext_stride : m.w0; d.H = m.H; d.W = m.W; d.qpd6 = m.q; d.status = 0;
             d.trace = j->h_trace ? j->h_trace + 1024 * i : nullptr;
             d.payload = j->device_emit ? j->d_slab + m.off_payload : nullptr;
@@ -306,7 +350,9 @@ int hevce_test_tu(const unsigned char *org, const unsigned char *nbr, int n, int
     HIPCHK(hipMemset(d, 0, total));
     HIPCHK(hipMemcpy(d + o_org, org, 1024, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d + o_nbr, nbr, 33 * 65, hipMemcpyHostToDevice));
-    if (hevce_launch_test_tu(d + o_org, d + o_nbr, n, qpd6, aL, aLB, aA, aAR, (short *)(d + o_lev), d + o_rec, (int *)(d + o_info), nullptr) != 0)
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (hevce_launch_test_tu(d + o_org, d + o_nbr, n, qpd6, aL, aLB, aA, aAR, (short *)(d + o_lev), d + o_rec, (int *)(d + o_info), qlut_device(dev, qpd6), nullptr) != 0)
         return fail("test kernel launch failed");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(lev, d + o_lev, 35 * 2048, hipMemcpyDeviceToHost));
@@ -326,7 +372,9 @@ int hevce_test_chain(const unsigned char *org, const unsigned char *nbr, int n, 
     HIPCHK(hipMemset(d, 0, total));
     HIPCHK(hipMemcpy(d, org, 1024, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d + o_nbr, nbr, 33 * 65, hipMemcpyHostToDevice));
-    if (hevce_launch_test_chain(d, d + o_nbr, n, qpd6, aL, aLB, aA, aAR, d + o_scr, (int *)(d + o_info), nullptr) != 0)
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (hevce_launch_test_chain(d, d + o_nbr, n, qpd6, aL, aLB, aA, aAR, d + o_scr, (int *)(d + o_info), qlut_device(dev, qpd6), nullptr) != 0)
         return fail("test kernel launch failed");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(lev, d + o_scr + 35 * 2048, 35 * 2048, hipMemcpyDeviceToHost));

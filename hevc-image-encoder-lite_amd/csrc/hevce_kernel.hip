@@ -22,13 +22,14 @@ extern "C" int hevce_launch_analyse(const HevceImageDesc *d_images, int n, hipSt
 extern "C" __global__ void __launch_bounds__(64, 1)
 hevce_test_tu_kernel(const unsigned char *org /*32x32*/, const unsigned char *nbr /*33x65: row 0 = y-1, col 0 = x-1*/,
                      int n, int q, int aL, int aLB, int aA, int aAR,
-                     short *lev /*35 x 1024, scan order*/, unsigned char *rec /*35 x 1024*/, int *info /*35 x 4: sse,last,cbf,cgsig_lo*/) {
+                     short *lev /*35 x 1024, scan order*/, unsigned char *rec /*35 x 1024*/, int *info /*35 x 4: sse,last,cbf,cgsig_lo*/,
+                     const unsigned short *qlut) {
     HvLds &S = HV_S;
     const int tid = (int)threadIdx.x;
     hv_init_tables(S, q, tid);
     for (int p = tid; p < 1024; p += 64) S.org[p >> 5][p & 31] = org[p];
     for (int p = tid; p < 33 * 65; p += 64) S.rec[p / 65][HV_RX - 1 + p % 65] = nbr[p];
-    if (tid == 0) S.trace = nullptr;
+    if (tid == 0) { S.trace = nullptr; S.qlut = qlut; }
     __syncthreads();
     /* the single-wave block has no thread 64/128/300/384: build the angle tables, scan tables and contexts here */
     if (tid < 35) { S.ang[tid] = hv_ang[tid]; S.invang[tid] = hv_invang[tid]; }
@@ -60,8 +61,8 @@ hevce_test_tu_kernel(const unsigned char *org /*32x32*/, const unsigned char *nb
 }
 
 extern "C" int hevce_launch_test_tu(const unsigned char *org, const unsigned char *nbr, int n, int q, int aL, int aLB, int aA, int aAR,
-                                    short *lev, unsigned char *rec, int *info, hipStream_t stream) {
-    hipLaunchKernelGGL(hevce_test_tu_kernel, dim3(1), dim3(64), 0, stream, org, nbr, n, q, aL, aLB, aA, aAR, lev, rec, info);
+                                    short *lev, unsigned char *rec, int *info, const unsigned short *qlut, hipStream_t stream) {
+    hipLaunchKernelGGL(hevce_test_tu_kernel, dim3(1), dim3(64), 0, stream, org, nbr, n, q, aL, aLB, aA, aAR, lev, rec, info, qlut);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -69,7 +70,7 @@ extern "C" int hevce_launch_test_tu(const unsigned char *org, const unsigned cha
    reconstruction) of all 35 modes for ONE n x n CU at the CTU origin.  One wavefront runs the chain jobs in turn. --- */
 extern "C" __global__ void __launch_bounds__(64, 1)
 hevce_test_chain_kernel(const unsigned char *org, const unsigned char *nbr, int n, int q, int aL, int aLB, int aA, int aAR,
-                        unsigned char *scratch /*HEVCE_SCRATCH_BYTES*/, int *info /*35 x 16*/) {
+                        unsigned char *scratch /*HEVCE_SCRATCH_BYTES*/, int *info /*35 x 16*/, const unsigned short *qlut) {
     HvLds &S = HV_S;
     const int tid = (int)threadIdx.x;
     hv_init_tables(S, q, tid);
@@ -77,7 +78,7 @@ hevce_test_chain_kernel(const unsigned char *org, const unsigned char *nbr, int 
     for (int p = tid; p < 33 * 65; p += 64) S.rec[p / 65][HV_RX - 1 + p % 65] = nbr[p];
     if (tid < 35) { S.ang[tid] = hv_ang[tid]; S.invang[tid] = hv_invang[tid]; }   /* no thread 384 in a single-wave block */
     if (tid == 0) {
-        S.trace = nullptr;
+        S.trace = nullptr; S.qlut = qlut;
         int k = 0;
         for (int d = 0; d <= 6; d++)
             for (int y = (d < 4 ? d : 3); y >= 0 && d - y < 4; y--) { S.d4pos[k] = (u8)((y << 2) | (d - y)); S.d4idx[(y << 2) | (d - y)] = (u8)k; k++; }
@@ -107,7 +108,7 @@ hevce_test_chain_kernel(const unsigned char *org, const unsigned char *nbr, int 
     }
 }
 extern "C" int hevce_launch_test_chain(const unsigned char *org, const unsigned char *nbr, int n, int q, int aL, int aLB, int aA, int aAR,
-                                       unsigned char *scratch, int *info, hipStream_t stream) {
-    hipLaunchKernelGGL(hevce_test_chain_kernel, dim3(1), dim3(64), 0, stream, org, nbr, n, q, aL, aLB, aA, aAR, scratch, info);
+                                       unsigned char *scratch, int *info, const unsigned short *qlut, hipStream_t stream) {
+    hipLaunchKernelGGL(hevce_test_chain_kernel, dim3(1), dim3(64), 0, stream, org, nbr, n, q, aL, aLB, aA, aAR, scratch, info, qlut);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

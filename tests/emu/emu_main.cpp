@@ -72,6 +72,12 @@ int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, 
     im.dump = dump;
     if (payload) { im.payload = payload; im.payload_len = payload_len; }     /* the kernel's stream writer on */
     im.flags = flags; im.stats = stats;
+    static std::vector<uint16_t> qlut[5];                    /* the quantiser's level tables, as the host builds them */
+    if (qlut[q].empty()) {
+        qlut[q].resize(4 * HEVCE_QLUT_N);
+        for (int t = 0; t < 4; t++) for (int av = 0; av < HEVCE_QLUT_N; av++) qlut[q][t * HEVCE_QLUT_N + av] = (uint16_t)hv_qlut_entry(q, t, av);
+    }
+    im.qlut = qlut[q].data();
     std::vector<uint8_t> wrtok(HEVCE_WRTOK_BYTES, 0xEF);
     im.wr_tok = wrtok.data();
     im.src_h = src_h; im.src_w = src_w; im.src_stride = src_w; im.qpd6 = q;
