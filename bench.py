@@ -2,11 +2,15 @@
 """bench.py -- BASELINE.json metric: Mpixels/s encoded (bit-exact .h265) at qpd6=2.
 
 A step = one pass of the hot path over one batch of synthetic input: every rank encodes ONE 3840x2160 G2-16 picture
-(BASELINE.json configs[1]; pads to 3840x2176 = 8160 CTUs) that is already resident in HBM: analysis
-analysis kernel (which also emits the slice data) -> D2H of the decision records and the slice data behind a
-host-written header -> complete .h265 bytes.  Images are independent, so with
-N ranks each rank encodes its own picture (seed + rank, weak scaling, no data-path collective); the only exchange is
-the gather of the finished streams to rank 0 over RCCL, inside the timed region.
+(BASELINE.json configs[1]; pads to 3840x2176 = 8160 CTUs) that is already resident in HBM: analysis kernel
+(which also writes the slice data) -> D2H of the slice data behind a host-written header -> complete .h265 bytes.  Pictures
+are independent, so with N ranks each rank encodes its own picture (seed + rank, weak scaling, no data-path collective); the
+only exchange is the gather of the finished streams on rank 0 (RCCL over xGMI), inside the timed region.
+
+Next to the headline `value`, computed ONCE outside the --steps loop and gated on the time already spent (extra keys of the
+same JSON line): BASELINE.json configs[2] (this rank's longest-first shard of 1024 x 1920x1080 pictures) and configs[3] (this
+rank's tiles of one 16384x16384 picture as 256 tile-pictures of 1024x1024), and the CPU baselines (the real reference on one
+core and on all of this box's cores, bounded samples).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -14,6 +18,7 @@ Rank 0 prints ONE JSON line.
 """
 import argparse
 import hashlib
+import importlib
 import json
 import os
 import sys
@@ -26,6 +31,18 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ALGO_BYTES_PER_PIXEL = 4.125   # 1 B luma read + 1 B recon written + 2.125 B decision record
+T_START = time.perf_counter()
+
+
+def _ref_encode(args):
+    """worker of the all-cores baseline: one reference encode per process"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    img, q = args
+    fn = orc.encode_ref if orc.ref() is not None else orc.encode
+    t = time.perf_counter()
+    s, _ = fn(img, q)
+    return time.perf_counter() - t, len(s)
 
 
 def cpu_baseline(img_full, qpd6):
@@ -44,15 +61,38 @@ def cpu_baseline(img_full, qpd6):
             "host_cores": os.cpu_count()}
 
 
+def cpu_baseline_all_cores(img_full, qpd6):
+    """the all-cores figure -- one reference process per core this box lets us use (its CPU share: 16 per GPU),
+    each encoding its own 384x256 crop (96 CTUs) of the workload image."""
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    H, W = img_full.shape
+    crops = []
+    for k in range(cores):
+        y = (k * 256) % max(H - 256, 1); x = (k * 384) % max(W - 384, 1)
+        crops.append((np.ascontiguousarray(img_full[y:y + 256, x:x + 384]), qpd6))
+    t = time.perf_counter()
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(_ref_encode, crops)
+    dt = time.perf_counter() - t
+    px = sum(c[0].size for c in crops)
+    return {"value": round(px / dt / 1e6, 5), "unit": "Mpixels/s", "cores": cores, "kind": "reference" if orc.ref() is not None else "port",
+            "sample": f"{cores} processes x one 384x256 crop (96 CTUs) each, wall {dt:.1f} s (pool start-up included)", "host_cores": os.cpu_count()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--qpd6", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip configs 3 / 4 and the all-cores baseline")
+    ap.add_argument("--time-budget", type=float, default=420.0, help="seconds after which the optional legs are skipped")
     args = ap.parse_args()
 
     import torch
@@ -60,6 +100,7 @@ def main():
     import hevce_pkg
     import hevce_workload as wl
     hevce = hevce_pkg.load()
+    D = importlib.import_module(hevce.__name__ + ".distributed")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -75,11 +116,10 @@ def main():
     d_img = torch.from_numpy(img).to(dev)                      # the input is resident in HBM before timing starts
     H, W = hevce.pad32(args.height), hevce.pad32(args.width)
     nctu = (H // 32) * (W // 32)
-    stream_obj = torch.cuda.current_stream(dev)
 
     job = hevce.Job([img.shape], args.qpd6, device=local)
     job.set_device_image(0, d_img.data_ptr(), keepalive=d_img)
-    job.set_stream(stream_obj.cuda_stream)
+    job.use_stream(torch.cuda.current_stream(dev).cuda_stream)   # the kernel is ordered behind whatever produced d_img on torch's stream
 
     gathered = {}
 
@@ -87,17 +127,10 @@ def main():
         job.run()                                              # kernel + D2H + header: .h265 complete
         s = job.stream(0)
         if world > 1:                                          # gather the finished streams on rank 0 (RCCL over xGMI)
-            n = torch.tensor([len(s)], dtype=torch.int64, device=dev)
-            lens = [torch.zeros_like(n) for _ in range(world)]
-            dist.all_gather(lens, n)
-            mx = int(max(int(v.item()) for v in lens))
-            buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
-            buf[:len(s)] = torch.frombuffer(bytearray(s), dtype=torch.uint8).to(dev)
-            out = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-            dist.gather(buf, out, dst=0)
+            got = D.gather_streams([s], device=dev)
             if rank == 0:
                 for r in range(world):
-                    gathered[r] = bytes(out[r][:int(lens[r].item())].cpu().numpy())
+                    gathered[r] = got[r][0]
         return s
 
     def sync():
@@ -125,29 +158,92 @@ def main():
         e = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         elapsed = float(e.item())
+    redo, bad = job.stats(0)
+    job.close()
 
     pixels_per_step = H * W * world
     value = pixels_per_step * args.steps / elapsed / 1e6
     k_avg = float(np.mean(kernel_ms))
     achieved = ALGO_BYTES_PER_PIXEL * H * W / (k_avg * 1e-3) / 1e9
     # HBM traffic cannot be counted from inside this process: it comes from the committed rocprofv3 --pmc passes of this
-    # kernel (profiles/pmc_traffic.json, bytes per CTU) scaled to this launch's CTU count; null when that file is absent
-    traffic = None
+    # kernel (profiles/pmc_traffic.json, bytes per CTU, measured on a 960x544 picture) SCALED to this launch's CTU count
+    traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = round(json.load(f)["hbm_bytes_per_ctu"] * nctu)
+            pj = json.load(f)
+            traffic = round(pj["hbm_bytes_per_ctu"] * nctu)
+            traffic_src = pj.get("scaled_from", "960x544")
     except Exception:
         traffic = None
-    # the bound that actually holds: VALU issue of the one compute unit a picture occupies -- from the committed
-    # instruction-mix PMC passes of this kernel (profiles/r01_pmc_instmix.json); informational, next to the mandated HBM figures
-    valu = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_instmix.json")) as f:
-            m = json.load(f)
-            valu = {"valu_issue_utilisation_of_the_cu": round(m["valu_issue_utilisation_of_the_cu"], 3),
-                    "valu_insts_per_ctu": round(m["valu_insts_per_ctu"]), "cu_cycles_per_ctu": round(m["cu_cycles_per_ctu"])}
-    except Exception:
-        valu = None
+
+    extras = {}
+
+    def left():
+        return args.time_budget - (time.perf_counter() - T_START)
+
+    def all_max(x):
+        if world == 1:
+            return x
+        e = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        return float(e.item())
+
+    go = (not args.no_extras) and all_max(-left()) < -120.0          # every rank takes the same decision
+    if go:
+        # ---- BASELINE.json configs[2] / SURVEY 8(d) config 3: 1024 x 1920x1080, this rank's longest-first shard, launches of <= 256
+        n3, h3, w3, uniq = 1024, 1080, 1920, 4
+        sizes = [(h3, w3)] * n3
+        mine = D.shard_batch(sizes, world)[rank]
+        pics = {k: wl.gen_g2(h3, w3, 16, seed=0x1234ABCD + k) for k in sorted({i % uniq for i in mine})}   # 4 different pictures: short host side
+        sync()
+        t3 = time.perf_counter()
+        launches = []
+
+        def enc(part):
+            with hevce.Job([sizes[i] for i in part], args.qpd6, device=local) as jb:
+                for j, i in enumerate(part):
+                    jb.upload(j, pics[i % uniq])
+                jb.run()
+                launches.append(jb.timings()["kernel_ms"])
+                return [jb.stream(j) for j in range(len(part))]
+        streams = D.encode_shard(enc, mine, per_launch=256)
+        digest = sorted((i, hashlib.sha256(streams[i]).hexdigest()[:16]) for i in mine)
+        got = D.gather_streams([json.dumps(digest).encode()], device=dev)     # the table of (index, hash); the streams themselves stay put
+        sync()
+        dt3 = all_max(time.perf_counter() - t3)
+        if rank == 0:
+            table = sorted(tuple(x) for part in got for x in json.loads(part[0].decode()))
+            ok = [i for i, _ in table] == list(range(n3)) and all(hsh == table[i % uniq][1] for i, hsh in table)
+            H3, W3 = hevce.pad32(h3), hevce.pad32(w3)
+            extras["config3_batch_1024x1080p"] = {
+                "value": round(H3 * W3 * n3 / dt3 / 1e6, 2), "unit": "Mpixels/s", "wall_s": round(dt3, 2), "pictures": n3,
+                "pictures_this_rank": len(mine), "launches_this_rank": len(launches), "kernel_ms_per_launch": [round(x, 1) for x in launches],
+                "includes": "H2D uploads, kernels, D2H of the streams, SHA-256 of every stream, gather of the hash table",
+                "all_streams_collected_and_consistent": bool(ok)}
+    if go and all_max(-left()) < -60.0:
+        # ---- BASELINE.json configs[3] / config 4: one 16384x16384 picture as 256 tile-pictures of 1024x1024, this rank's tiles
+        big, tile = 16384, 1024
+        cols = big // tile
+        tiles = list(range(cols * cols))
+        mine = D.shard_batch([(tile, tile)] * len(tiles), world)[rank]
+        rows_needed = sorted({t // cols for t in mine})
+        band = {r: wl.gen_g2(tile, big, 16, seed=0x1234ABCD + 1000 + r) for r in rows_needed[:4]}       # at most 4 different bands of the big picture
+        keys = sorted(band)
+        sync()
+        t4 = time.perf_counter()
+        with hevce.Job([(tile, tile)] * len(mine), args.qpd6, device=local) as jb:
+            for j, t in enumerate(mine):
+                jb.upload_window(j, band[keys[(t // cols) % len(keys)]], 0, (t % cols) * tile)
+            jb.run()
+            k4 = jb.timings()["kernel_ms"]
+            nbytes = sum(len(jb.stream(j)) for j in range(len(mine)))
+        sync()
+        dt4 = all_max(time.perf_counter() - t4)
+        if rank == 0:
+            extras["config4_16384x16384_as_256_tiles"] = {
+                "value": round(big * big / dt4 / 1e6, 2), "unit": "Mpixels/s", "wall_s": round(dt4, 2), "tiles": len(tiles), "tiles_this_rank": len(mine),
+                "kernel_ms": round(k4, 1), "stream_bytes_this_rank": nbytes,
+                "note": "tile-pictures with their own headers (the reference crops at 8192); parity per tile: tests/test_gpu_tiles.py"}
 
     if rank == 0:
         line = {
@@ -157,25 +253,29 @@ def main():
             "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {"workload": f"one {args.width}x{args.height} G2-16 grayscale picture per GPU (seed 0x1234ABCD+rank), "
                                    f"qpd6={args.qpd6}, padded {W}x{H} = {nctu} CTUs, input resident in HBM; "
-                                   "kernel (analysis + slice-data emission) + D2H + header" + ("; RCCL gather of streams to rank 0" if world > 1 else ""),
+                                   "kernel (analysis + slice data) + D2H + header" + ("; RCCL gather of streams to rank 0" if world > 1 else ""),
                        "images_per_gpu": 1, "parallelism": f"image-per-gpu x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 6), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 9), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 9), "traffic": traffic, "traffic_scaled_from": traffic_src,
                          "kernel": "hevce_analyse_kernel", "kernel_ms_avg": round(k_avg, 3),
                          "us_per_ctu": round(k_avg * 1e3 / nctu, 2),
-                         "note": "serial-dependency bound by construction (SURVEY 0.2): one picture = one workgroup chain",
-                         "valu_issue": valu},
+                         "note": "serial-dependency bound by construction (SURVEY 0.2): one picture = one chain of CABAC-costed decisions; "
+                                 "the bound that holds is instruction issue on the compute unit the picture occupies (DESIGN.md 6)"},
             "phases_ms": {"kernel": round(k_avg, 2), "d2h": round(float(np.mean(d2h_ms)), 2), "host_assembly": round(float(np.mean(writer_ms)), 2)},
+            "ctus_analysed_twice": redo, "coder_mismatches": bad,
             "stream_bytes": len(first), "stream_sha256": hashlib.sha256(first).hexdigest(),
         }
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(img, args.qpd6)
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu_1core"] = round(value / cb["value"], 2)
+            if not args.no_extras and left() > 45.0:
+                ca = cpu_baseline_all_cores(img, args.qpd6)
+                line["cpu_baseline_all_cores"] = ca
         if world > 1:
             line["gathered_streams"] = len(gathered)
         print(json.dumps(line), flush=True)
-    job.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -61,6 +61,7 @@ def lib():
         L.HEVCImageEncoderTiles.restype = C.c_int
         L.HEVCImageEncoderTiles.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_u8p), _i32p, C.POINTER(_u8p)]
         L.hevce_job_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.hevce_job_use_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.hevce_job_set_flags.argtypes = [C.c_void_p, C.c_int]
         L.hevce_job_stats.argtypes = [C.c_void_p, C.c_int, _i32p]
         for f in ("hevce_job_run", "hevce_job_launch", "hevce_job_finish"):
@@ -189,6 +190,10 @@ class Job:
 
     def set_stream(self, hip_stream):
         _check(lib().hevce_job_set_stream(self._h, C.c_void_p(hip_stream)), "hevce_job_set_stream")
+
+    def use_stream(self, hip_stream_handle):
+        """run on exactly this stream handle; 0 = the NULL (legacy default) stream, e.g. torch.cuda.current_stream().cuda_stream"""
+        _check(lib().hevce_job_use_stream(self._h, C.c_void_p(int(hip_stream_handle))), "hevce_job_use_stream")
 
     def run(self):
         _check(lib().hevce_job_run(self._h), "hevce_job_run")

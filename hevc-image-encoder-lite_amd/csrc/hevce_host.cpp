@@ -99,10 +99,23 @@ struct Image {
     size_t hoff_rec, hoff_state, hoff_plen;                      /* into the pinned host slab */
     const void *ext_img = nullptr;
     long ext_stride = 0;                                         /* row stride of ext_img (0: w0) */
-    std::vector<uint8_t> stream;
+    std::vector<uint8_t> stream;                                 /* host-writer mode only */
+    const uint8_t *stream_ptr = nullptr;                         /* the finished .h265: in the job's pinned stream slab (or `stream`) */
     int length = 0;
 };
 
+}  // namespace
+
+struct hevce_job;
+extern "C" void hevce_job_destroy(hevce_job *job);
+namespace {
+/* HEVCImageEncoder()'s per-thread job context (see there) */
+std::atomic<bool> g_alive{true};                             /* false once the process is exiting: the HIP runtime may be gone */
+struct CachedJob {
+    hevce_job *j = nullptr; int device = -1, h = 0, w = 0, q = -1;
+    ~CachedJob() { if (j && g_alive.load()) hevce_job_destroy(j); }
+};
+thread_local CachedJob g_cached;
 }  // namespace
 
 struct hevce_job {
@@ -112,7 +125,8 @@ struct hevce_job {
     size_t d_bytes = 0, h_bytes = 0;
     HevceImageDesc *d_desc = nullptr;
     std::vector<HevceImageDesc> h_desc;
-    bool desc_dirty = true, launched = false;
+    bool desc_dirty = true, launched = false, records_fetched = false;
+    uint8_t *h_streams = nullptr; size_t h_streams_bytes = 0;   /* pinned: header + slice data of every picture, back to back; grows on demand */
     bool device_emit = true;         /* the kernel emits the slice data itself; HEVCE_HOST_WRITER=1: replay the records on the host instead */
     int flags = 0;                   /* HevceImageDesc.flags (tests: HEVCE_FLAGS) */
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -188,6 +202,7 @@ void hevce_job_destroy(hevce_job *j) {
     if (j->d_slab) (void)hipFree(j->d_slab);
     if (j->d_desc) (void)hipFree(j->d_desc);
     if (j->h_slab) (void)hipHostFree(j->h_slab);
+    if (j->h_streams) (void)hipHostFree(j->h_streams);
     if (j->h_trace) (void)hipHostFree(j->h_trace);
     if (j->d_dump) (void)hipFree(j->d_dump);
     if (j->ev0) (void)hipEventDestroy(j->ev0);
@@ -202,8 +217,8 @@ int hevce_job_upload(hevce_job *j, int i, const unsigned char *img) {
     HIPCHK(hipSetDevice(j->device));
     Image &m = j->im[i];
     m.ext_img = nullptr; m.ext_stride = 0; j->desc_dirty = true;
+    /* stream-ordered before the kernel; a pageable source has been staged when the call returns, so the caller may reuse it */
     HIPCHK(hipMemcpyAsync(j->d_slab + m.off_img, img, size_t(m.h0) * m.w0, hipMemcpyHostToDevice, j->stream));
-    HIPCHK(hipStreamSynchronize(j->stream));
     return 0;
 }
 
@@ -214,7 +229,6 @@ int hevce_job_upload_window(hevce_job *j, int i, const unsigned char *origin, lo
     Image &m = j->im[i];
     m.ext_img = nullptr; m.ext_stride = 0; j->desc_dirty = true;
     HIPCHK(hipMemcpy2DAsync(j->d_slab + m.off_img, size_t(m.w0), origin, size_t(stride), size_t(m.w0), size_t(m.h0), hipMemcpyHostToDevice, j->stream));
-    HIPCHK(hipStreamSynchronize(j->stream));
     return 0;
 }
 
@@ -234,6 +248,13 @@ int hevce_job_set_device_window(hevce_job *j, int i, const void *d_origin, long 
 int hevce_job_set_stream(hevce_job *j, void *s) {
     if (!j) return fail("hevce_job_set_stream: null job");
     j->stream = s ? (hipStream_t)s : j->own_stream;
+    return 0;
+}
+/* run on exactly this stream handle; 0 is the NULL (legacy default) stream -- torch's default current stream has handle 0 --
+   and not "the job's own stream" as in hevce_job_set_stream */
+int hevce_job_use_stream(hevce_job *j, void *s) {
+    if (!j) return fail("hevce_job_use_stream: null job");
+    j->stream = (hipStream_t)s;
     return 0;
 }
 
@@ -280,13 +301,17 @@ int hevce_job_launch(hevce_job *j) {
     HIPCHK(hipEventRecord(j->ev0, j->stream));
     if (hevce_launch_analyse(j->d_desc, j->n, j->stream) != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     HIPCHK(hipEventRecord(j->ev1, j->stream));
-    /* records and per-CTU states are contiguous per image; copy image by image into the pinned slab */
+    /* what the host needs in every case: the length of each picture's slice data.  The decision records and per-CTU coder
+       registers (2176 + 32 bytes per CTU) only travel when somebody wants them: the host-writer mode, hevce_job_download_records */
     for (int i = 0; i < j->n; i++) {
         const Image &m = j->im[i];
-        HIPCHK(hipMemcpyAsync(j->h_slab + m.hoff_rec, j->d_slab + m.off_rec, size_t(m.nctu) * HEVCE_REC_BYTES, hipMemcpyDeviceToHost, j->stream));
-        HIPCHK(hipMemcpyAsync(j->h_slab + m.hoff_state, j->d_slab + m.off_state, size_t(m.nctu) * 32, hipMemcpyDeviceToHost, j->stream));
         if (j->device_emit) HIPCHK(hipMemcpyAsync(j->h_slab + m.hoff_plen, j->d_slab + m.off_plen, 4, hipMemcpyDeviceToHost, j->stream));
+        else {
+            HIPCHK(hipMemcpyAsync(j->h_slab + m.hoff_rec, j->d_slab + m.off_rec, size_t(m.nctu) * HEVCE_REC_BYTES, hipMemcpyDeviceToHost, j->stream));
+            HIPCHK(hipMemcpyAsync(j->h_slab + m.hoff_state, j->d_slab + m.off_state, size_t(m.nctu) * 32, hipMemcpyDeviceToHost, j->stream));
+        }
     }
+    j->records_fetched = !j->device_emit;
     HIPCHK(hipEventRecord(j->ev2, j->stream));
     j->launched = true;
     return 0;
@@ -301,16 +326,34 @@ int hevce_job_finish(hevce_job *j) {
     HIPCHK(hipEventElapsedTime(&j->d2h_ms, j->ev1, j->ev2));
     const auto t0 = std::chrono::steady_clock::now();
     if (j->device_emit) {
-        /* the kernel has emitted the slice data; the host only puts the VPS/SPS/PPS/slice header in front  [ref :625-691] */
+        /* the kernel has written the slice data; the host puts the VPS/SPS/PPS/slice header in front  [ref :625-691].  The streams
+           live back to back in one pinned slab (grown on demand, kept for the next run): header written in place, slice data
+           fetched by one asynchronous copy per picture of exactly its length, one wait for all of them */
+        size_t need = 0;
         for (int i = 0; i < j->n; i++) {
             Image &m = j->im[i];
             const int plen = *(const int32_t *)(j->h_slab + m.hoff_plen);
             if (plen <= 0 || size_t(plen) > size_t(m.nctu) * 3200 + 64) return fail("image %d: the device emitted %d bytes", i, plen);
-            m.stream.resize((size_t)hevce_stream_bound(m.h0, m.w0));
-            const int hdr = hevce_write_header(m.stream.data(), m.q, m.H, m.W);
-            HIPCHK(hipMemcpy(m.stream.data() + hdr, j->d_slab + m.off_payload, size_t(plen), hipMemcpyDeviceToHost));
-            m.length = hdr + plen;
+            need += 128 + size_t(plen);
         }
+        if (need > j->h_streams_bytes) {
+            if (j->h_streams) (void)hipHostFree(j->h_streams);
+            j->h_streams = nullptr; j->h_streams_bytes = 0;
+            const size_t cap = need + need / 4 + 4096;
+            HIPCHK(hipHostMalloc((void **)&j->h_streams, cap, hipHostMallocDefault));
+            j->h_streams_bytes = cap;
+        }
+        size_t off = 0;
+        for (int i = 0; i < j->n; i++) {
+            Image &m = j->im[i];
+            const int plen = *(const int32_t *)(j->h_slab + m.hoff_plen);
+            uint8_t *dst = j->h_streams + off;
+            const int hdr = hevce_write_header(dst, m.q, m.H, m.W);
+            HIPCHK(hipMemcpyAsync(dst + hdr, j->d_slab + m.off_payload, size_t(plen), hipMemcpyDeviceToHost, j->stream));
+            m.stream_ptr = dst; m.length = hdr + plen;
+            off += 128 + size_t(plen);
+        }
+        HIPCHK(hipStreamSynchronize(j->stream));
         j->writer_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return 0;
     }
@@ -327,6 +370,8 @@ int hevce_job_finish(hevce_job *j) {
             Image &m = j->im[i];
             m.stream.resize((size_t)hevce_stream_bound(m.h0, m.w0));
             m.length = hevce_write_stream(m.stream.data(), j->h_slab + m.hoff_rec, m.H, m.W, m.q);
+            m.stream.resize((size_t)m.length);
+            m.stream_ptr = m.stream.data();
         }
     };
     if (nthreads <= 1) work();
@@ -410,7 +455,7 @@ int hevce_job_run(hevce_job *j) {
 const unsigned char *hevce_job_stream(hevce_job *j, int i, int *length) {
     if (!j || i < 0 || i >= j->n) { fail("hevce_job_stream: bad arguments"); return nullptr; }
     if (length) *length = j->im[i].length;
-    return j->im[i].stream.data();
+    return j->im[i].stream_ptr;
 }
 
 int hevce_job_padded_size(hevce_job *j, int i, int *ysz, int *xsz) {
@@ -434,6 +479,12 @@ void *hevce_job_device_records(hevce_job *j, int i) { return (j && i >= 0 && i <
 int hevce_job_download_records(hevce_job *j, int i, unsigned char *records, int *ctu_state) {
     if (!j || i < 0 || i >= j->n) return fail("hevce_job_download_records: bad arguments");
     const Image &m = j->im[i];
+    if (!j->records_fetched) {                                   /* fetched on demand: the default path never needs them on the host */
+        HIPCHK(hipSetDevice(j->device));
+        HIPCHK(hipMemcpy(records, j->d_slab + m.off_rec, size_t(m.nctu) * HEVCE_REC_BYTES, hipMemcpyDeviceToHost));
+        if (ctu_state) HIPCHK(hipMemcpy(ctu_state, j->d_slab + m.off_state, size_t(m.nctu) * 32, hipMemcpyDeviceToHost));
+        return 0;
+    }
     memcpy(records, j->h_slab + m.hoff_rec, size_t(m.nctu) * HEVCE_REC_BYTES);
     if (ctu_state) memcpy(ctu_state, j->h_slab + m.hoff_state, size_t(m.nctu) * 32);
     return 0;
@@ -459,7 +510,7 @@ int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned 
     if (rc == 0) rc = hevce_job_run(j);
     for (int i = 0; i < n && rc == 0; i++) {
         const Image &m = j->im[i];
-        memcpy(pbuffers[i], m.stream.data(), (size_t)m.length);
+        memcpy(pbuffers[i], m.stream_ptr, (size_t)m.length);
         if (lengths) lengths[i] = m.length;
         rc = hevce_job_download_rcon(j, i, img_rcons[i]);
         yszs[i] = m.H; xszs[i] = m.W;
@@ -493,7 +544,7 @@ int HEVCImageEncoderTiles(const unsigned char *img, int ysz, int xsz, int tile_y
     if (rc == 0) rc = hevce_job_run(j);
     for (int t = 0; t < n && rc == 0; t++) {
         const Image &m = j->im[t];
-        memcpy(pbuffers[t], m.stream.data(), (size_t)m.length);
+        memcpy(pbuffers[t], m.stream_ptr, (size_t)m.length);
         if (lengths) lengths[t] = m.length;
         if (img_rcons && img_rcons[t]) rc = hevce_job_download_rcon(j, t, img_rcons[t]);
     }
@@ -501,15 +552,31 @@ int HEVCImageEncoderTiles(const unsigned char *img, int ysz, int xsz, int tile_y
     return rc == 0 ? n : -1;
 }
 
+/* The reference's entry point  [ref src/HEVCe.h:5-12, HEVCe.c:1570-1647].  The reference keeps no state between calls and is
+   re-entrant (everything on the caller's stack, HEVCe.c:1578-1593); here every calling THREAD keeps one job context alive between
+   calls -- device slab, pinned buffers, stream and events of the last (size, qpd6) it encoded -- so that a caller looping over
+   pictures of one size pays for the allocations once.  Threads never share a context: concurrent callers are independent. */
 __attribute__((visibility("default"))) int HEVCImageEncoder(unsigned char *pbuffer, const unsigned char *img, unsigned char *img_rcon,
                      int *ysz, int *xsz, const int qpd6) {
-    int len = 0;
-    unsigned char *pb[1] = { pbuffer };
-    const unsigned char *im[1] = { img };
-    unsigned char *rc[1] = { img_rcon };
-    const int q[1] = { qpd6 };
-    if (HEVCImageEncoderBatch(1, pb, im, rc, ysz, xsz, q, &len) != 0) return -1;
-    return len;
+    if (!pbuffer || !img || !img_rcon || !ysz || !xsz) return fail("HEVCImageEncoder: null argument");
+    int device = 0;
+    if (const char *e = getenv("HEVCE_DEVICE")) device = atoi(e);
+    CachedJob &c = g_cached;
+    if (!c.j || c.device != device || c.h != *ysz || c.w != *xsz || c.q != qpd6) {
+        if (c.j) hevce_job_destroy(c.j);
+        c.j = hevce_job_create(device, 1, ysz, xsz, &qpd6);
+        if (!c.j) return -1;
+        c.device = device; c.h = *ysz; c.w = *xsz; c.q = qpd6;
+        static std::once_flag once;
+        std::call_once(once, [] { atexit([] { g_alive.store(false); }); });   /* after HIP's own registration: runs before its teardown */
+    }
+    hevce_job *j = c.j;
+    if (hevce_job_upload(j, 0, img) != 0 || hevce_job_run(j) != 0) { hevce_job_destroy(j); c.j = nullptr; return -1; }
+    const Image &m = j->im[0];
+    memcpy(pbuffer, m.stream_ptr, (size_t)m.length);
+    if (hevce_job_download_rcon(j, 0, img_rcon) != 0) return -1;
+    *ysz = m.H; *xsz = m.W;
+    return m.length;
 }
 
 #pragma GCC visibility pop

@@ -62,6 +62,9 @@ int  hevce_job_set_device_image(hevce_job *job, int i, const void *d_img);
 int  hevce_job_set_device_window(hevce_job *job, int i, const void *d_origin, long stride);
 /* run on this hipStream_t (NULL = the job's own stream) */
 int  hevce_job_set_stream(hevce_job *job, void *hip_stream);
+/* run on exactly this hipStream_t handle, where 0 means the NULL (legacy default) stream -- e.g. torch's default current stream;
+   uploads, the kernel and the result copies are then ordered behind whatever the caller enqueued there before */
+int  hevce_job_use_stream(hevce_job *job, void *hip_stream);
 /* analysis kernel over all images (it also emits each image's slice data) + D2H of the decision records and of the
    slice data behind a host-written VPS/SPS/PPS/slice header.  0 on success.
    HEVCE_HOST_WRITER=1 in the environment: the host replays the decision records into the stream instead (cross-check) */

@@ -188,3 +188,71 @@ def test_device_emitted_stream_equals_host_writer_replay():
     c = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert b.returncode == 0 and c.returncode == 0, (b.stderr, c.stderr)
     assert b.stdout.strip() == c.stdout.strip() and len(b.stdout.split()) == 3
+
+
+def test_1080p_pictures_in_one_launch_match_reference_hashes(hevce):
+    """BASELINE.json configs[2] picture size: eight 1920x1080 G2-16 pictures (the seeds bench.py / tools/dist_batch.py use) in ONE
+    launch against SHA-256s produced by the REAL reference in the build container (oracle/gen_golden_1080p.py)."""
+    import json
+    import hevce_workload as wl
+    path = os.path.join(GOLD, "manifest_1080p.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/manifest_1080p.json not generated")
+    gold = json.load(open(path))
+    imgs = [wl.gen_g2(g["h"], g["w"], 16, seed=g["seed"]) for g in gold]
+    with hevce.Job([im.shape for im in imgs], 2) as job:
+        for i, im in enumerate(imgs):
+            job.upload(i, im)
+        job.run()
+        for i, g in enumerate(gold):
+            s = job.stream(i)
+            assert len(s) == g["len"] and hashlib.sha256(s).hexdigest() == g["sha256"], i
+            assert hashlib.sha256(job.rcon(i).tobytes()).hexdigest() == g["rcon_sha256"], i
+            assert job.stats(i)[1] == 0
+
+
+def test_concurrent_callers_of_the_drop_in_symbol(hevce):
+    """The reference's entry point is re-entrant (all state on the caller's stack, HEVCe.c:1578-1593): four threads call
+    HEVCImageEncoder at the same time on different pictures (each thread several times: its cached job context is reused, and
+    rebuilt when the size changes) -- every result is the golden one."""
+    import threading
+    cases = [load_case(p) for p in small_cases() if any(k in p for k in ("g2_16_64x96_q2", "lcg_100x70_q2", "noise_64x64_q1", "checker_64x64_q2"))]
+    assert len(cases) == 4
+    errors = []
+
+    def worker(k):
+        try:
+            for rep in range(3):
+                c = cases[(k + rep) % 4] if rep == 2 else cases[k]      # the last call changes the picture size
+                stream, rcon = hevce.HEVCImageEncoder(c["img"], c["q"])
+                if stream != c["stream"] or not np.array_equal(rcon, c["rcon"]):
+                    errors.append((k, rep))
+        except Exception as e:                                          # noqa: BLE001
+            errors.append((k, repr(e)))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == []
+
+
+def test_job_is_ordered_behind_the_callers_stream(hevce, orc):
+    """hevce_job_use_stream(0) = the NULL stream torch's default stream maps to: a picture produced asynchronously on torch's
+    current stream (no host synchronisation in between) is what the kernel reads."""
+    import torch
+    import hevce_workload as wl
+    dev = torch.device("cuda", 0)
+    img = wl.gen_g2(96, 160, 16, seed=99)
+    want, _ = orc.encode(img, 2)
+    src = torch.from_numpy(img.astype(np.int16) + 7).to(dev)
+    big = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=dev)
+    with hevce.Job([img.shape], 2) as job:
+        job.use_stream(torch.cuda.current_stream(dev).cuda_stream)
+        for _ in range(3):
+            d = torch.zeros(img.shape, dtype=torch.uint8, device=dev)
+            job.set_device_image(0, d.data_ptr(), keepalive=d)
+            big.normal_()                                           # a long-running producer first ...
+            d.copy_((src - 7).to(torch.uint8))                      # ... then the picture, both only enqueued
+            job.run()
+            assert job.stream(0) == want

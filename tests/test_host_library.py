@@ -103,3 +103,18 @@ def test_partition_of_a_batch_over_ranks(hevce):
     assert sh.waves([(1080, 1920)] * 300) == (2, 2 * 2040) and sh.waves([]) == (0, 0)
     with pytest.raises(ValueError):
         sh.partition_lpt(sizes, 0)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/HEVCeMain.c"), reason="reference sources not present (build container only)")
+def test_reference_cli_links_against_the_library(hevce, tmp_path):
+    """the reference's own main() (src/HEVCeMain.c, compiled where it lies, nothing copied) links against
+    libhevce_mi355x.so in place of src/HEVCe.c -- the drop-in symbol has the reference's name, signature and linkage.  Link
+    only: without a GPU the call itself reports failure."""
+    exe = tmp_path / "HEVCe_with_lib"
+    libdir = os.path.dirname(hevce.LIB_PATH)
+    subprocess.check_call(["gcc", "-O1", "-w", "-o", str(exe), "/root/reference/src/HEVCeMain.c", "-I/root/reference/src",
+                           "-L" + libdir, "-lhevce_mi355x", "-lm", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output(["nm", "-D", "--undefined-only", str(exe)]).decode()
+    assert "HEVCImageEncoder" in out
+    p = subprocess.run([str(exe)], capture_output=True)                 # no arguments: the reference's usage text, exit -1
+    assert p.returncode == 255 and b"Usage" in p.stdout

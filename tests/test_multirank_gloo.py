@@ -1,103 +1,100 @@
-"""CPU: the N>1 path of bench.py's sharding/gather logic with world_size 2 over gloo (no GPU): every rank owns its own
-picture (seed + rank), encodes it independently (here with the oracle standing in for the device) and rank 0 gathers the
-finished streams; the gathered bytes must equal what each rank produced and what a single process produces."""
+"""CPU: the N>1 paths with world_size 2 over gloo (no GPU), through the SAME functions bench.py and tools/dist_batch.py use
+(hevc-image-encoder-lite_amd/distributed.py: gather_streams, shard_batch, encode_shard) -- only the encoder is replaced by the
+oracle, which stands in for the device here.  The gathered bytes must equal what a single process produces."""
 import hashlib
+import importlib
 import os
 import sys
-
-import numpy as np
-import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _setup(rank, world, port):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import torch
     import torch.distributed as dist
-    import hevce_workload as wl
-    import orc
+    import hevce_pkg
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    img = wl.gen_g2(64, 96, 16, seed=0x1234ABCD + rank)          # same sharding rule as bench.py
+    return dist, importlib.import_module(hevce_pkg.load().__name__ + ".distributed")
+
+
+def _worker(rank, world, port, q):
+    dist, D = _setup(rank, world, port)
+    import hevce_workload as wl
+    import orc
+    img = wl.gen_g2(64, 96, 16, seed=0x1234ABCD + rank)          # bench.py: every rank its own picture (seed + rank)
     s, _ = orc.encode(img, 2)
-    n = torch.tensor([len(s)], dtype=torch.int64)
-    lens = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(lens, n)
-    mx = int(max(int(v.item()) for v in lens))
-    buf = torch.zeros(mx, dtype=torch.uint8)
-    buf[:len(s)] = torch.frombuffer(bytearray(s), dtype=torch.uint8)
-    out = [torch.zeros(mx, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, out, dst=0)
+    got = D.gather_streams([s])                                  # bench.py's gather (RCCL there, gloo here)
     dist.barrier()
     if rank == 0:
-        q.put([hashlib.sha256(bytes(out[r][:int(lens[r].item())].numpy())).hexdigest() for r in range(world)])
+        q.put([hashlib.sha256(part[0]).hexdigest() for part in got])
+    else:
+        assert got is None
     dist.destroy_process_group()
 
 
-def test_two_ranks_gather_streams():
+def _run(target, world=2, base_port=29500):
     import torch.multiprocessing as mp
-    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import hevce_workload as wl
-    import orc
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = base_port + (os.getpid() % 2000)
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return got
+
+
+def test_two_ranks_gather_streams():
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hevce_workload as wl
+    import orc
+    got = _run(_worker)
     want = [hashlib.sha256(orc.encode(wl.gen_g2(64, 96, 16, seed=0x1234ABCD + r), 2)[0]).hexdigest() for r in range(2)]
     assert got == want and got[0] != got[1]
 
 
+SIZES = [(16 + 8 * (i % 5), 24 + 16 * (i % 3)) for i in range(11)]
+
+
 def _batch_worker(rank, world, port, q):
-    """the sharding + collection logic of tools/dist_batch.py (LPT partition, no data-path collective, one
-    all_gather_object of (index, length, sha) tables), with the oracle standing in for the device"""
-    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import importlib
-    import torch.distributed as dist
-    import hevce_pkg
+    """config 3 (a batch dealt out over the ranks): shard_batch + encode_shard + gather_streams, as tools/dist_batch.py
+    and bench.py's config-3 leg do; ragged shards (11 pictures over 2 ranks, launches of 4)"""
+    dist, D = _setup(rank, world, port)
     import hevce_workload as wl
     import orc
-    sharding = importlib.import_module(hevce_pkg.load().__name__ + ".sharding")
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    sizes = [(16 + 8 * (i % 5), 24 + 16 * (i % 3)) for i in range(11)]
-    mine = sharding.partition_lpt(sizes, world)[rank]
-    out = []
-    for i in mine:
-        s, _ = orc.encode(wl.gen_g2(sizes[i][0], sizes[i][1], 16, seed=0x1234ABCD + i), 2)
-        out.append((i, len(s), hashlib.sha256(s).hexdigest()))
-    table = [None] * world
-    dist.all_gather_object(table, out)
+    mine = D.shard_batch(SIZES, world)[rank]
+    enc = lambda part: [orc.encode(wl.gen_g2(SIZES[i][0], SIZES[i][1], 16, seed=0x1234ABCD + i), 2)[0] for i in part]
+    streams = D.encode_shard(enc, mine, per_launch=4)
+    got = D.gather_streams([streams[i] for i in mine])
     dist.barrier()
     if rank == 0:
-        q.put(sorted(x for part in table for x in part))
+        table = D.shard_batch(SIZES, world)
+        q.put(sorted((i, hashlib.sha256(s).hexdigest()) for r in range(world) for i, s in zip(table[r], got[r])))
     dist.destroy_process_group()
 
 
 def test_two_ranks_share_a_batch():
-    import torch.multiprocessing as mp
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hevce_workload as wl
     import orc
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    sizes = [(16 + 8 * (i % 5), 24 + 16 * (i % 3)) for i in range(11)]
-    want = []
-    for i, (h, w) in enumerate(sizes):
-        s, _ = orc.encode(wl.gen_g2(h, w, 16, seed=0x1234ABCD + i), 2)
-        want.append((i, len(s), hashlib.sha256(s).hexdigest()))
+    got = _run(_batch_worker, base_port=31500)
+    want = [(i, hashlib.sha256(orc.encode(wl.gen_g2(h, w, 16, seed=0x1234ABCD + i), 2)[0]).hexdigest()) for i, (h, w) in enumerate(SIZES)]
     assert got == want
+
+
+def _empty_worker(rank, world, port, q):
+    """a rank without pictures (more ranks than pictures) takes part in the gather with an empty list"""
+    dist, D = _setup(rank, world, port)
+    got = D.gather_streams([b"abc", b""] if rank == 1 else [])
+    dist.barrier()
+    if rank == 0:
+        q.put(got)
+    dist.destroy_process_group()
+
+
+def test_gather_with_an_empty_rank():
+    assert _run(_empty_worker, base_port=33500) == [[], [b"abc", b""]]
