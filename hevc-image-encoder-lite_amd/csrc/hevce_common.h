@@ -51,6 +51,27 @@ typedef struct HevceCoderRegs {
     int32_t  pad;
 } HevceCoderRegs;
 
+/* Cluster mode (two workgroups per picture, hevce_device.h hv_parent_worker): mailboxes in HBM between the workgroup that walks
+   the picture's chain of 8x8 decisions and the one that evaluates the enclosing 16x16 / 32x32 CUs for it.  index = CU level - 1. */
+typedef struct HevceMsg {      /* analysis workgroup -> parent workgroup: "evaluate this CU from this entry state" */
+    int32_t seq;               /* message number on this mailbox, written last (release); 0 = none yet */
+    int32_t kind;              /* 1 = evaluate, 2 = exit */
+    int32_t ctu, y, x, n;      /* the CU: CTU index, position inside the CTU, size */
+    int32_t range, nbits;      /* coder at the CU's entry (range half) */
+    int32_t split_inc, ml, ma; /* neighbour context  [ref HEVCe.c:1369-1373] */
+    int32_t L, LB, A, AR;      /* neighbour availability */
+    int32_t pad_;
+    uint8_t ctx[104];          /* contexts at the CU's entry */
+} HevceMsg;
+typedef struct HevceRes {      /* parent workgroup -> analysis workgroup: the best unsplit candidate */
+    int32_t seq;               /* = the message it answers, written last (release) */
+    int32_t cost, winner, sse; /* its cost, index (0..69) and distortion */
+    int32_t range, nbits;      /* coder after it (nbits with its bypass bins taken off) */
+    int32_t pad_[2];
+    uint8_t ctx[104];          /* contexts after it */
+} HevceRes;
+typedef struct HevceCluster { HevceMsg msg[2]; HevceRes res[2]; int32_t error; int32_t pad_[3]; } HevceCluster;
+
 /* one image of a batch, as the kernel sees it (all pointers are device pointers) */
 typedef struct HevceImageDesc {
     const uint8_t *img;       /* src_h x src_w luma, row stride src_stride (>= src_w: the picture may be a window of a larger one) */
@@ -69,6 +90,7 @@ typedef struct HevceImageDesc {
     uint8_t       *wr_tok;    /* HEVCE_WRTOK_BYTES: the token slots of the CTU the writer is encoding */
     int32_t       *payload_len;
     int32_t       *stats;     /* optional, 2 ints: CTUs analysed twice (EXACT after FAST), consistency failures (must be 0) */
+    HevceCluster  *cluster;   /* non-NULL: cluster mode, the launch has two workgroups per picture (2 i: chain, 2 i + 1: parents) */
     int32_t        flags;     /* tests: bit 0 EXACT engines throughout; bits 8-15 / 16-23: forced re-analysis periods (hevce_device.h) */
     int32_t        pad_;
 } HevceImageDesc;

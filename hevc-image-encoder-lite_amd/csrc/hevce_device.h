@@ -23,6 +23,12 @@
 #define HV_KEEP(x) do { } while (0)
 #define HV_NOUNROLL
 static inline unsigned hv_ldg_u32(const unsigned *p) { return *p; }
+void emu_yield(void);
+static inline void hv_publish_fence() { }
+static inline void hv_st_release(int *p, int v) { *p = v; }
+static inline int  hv_ld_acquire(const int *p) { return *p; }
+static inline void hv_spin_pause() { emu_yield(); }           /* lets the other workgroup's fibers run */
+static inline unsigned long long hv_realtime() { static unsigned long long t; return t += 1; }
 static inline unsigned hv_perm(unsigned a, unsigned b, unsigned sel) {
     const unsigned long long src = ((unsigned long long)a << 32) | b;
     unsigned r = 0;
@@ -90,6 +96,14 @@ template <typename T> static HD T *hv_uni_ptr(T *p) {
     const unsigned long long a = (unsigned long long)p;
     return (T *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a));
 }
+/* cluster mode: hand-off between two workgroups through HBM.  Payload first (plain stores by any thread), hv_publish_fence() by
+   every thread that stored, a workgroup barrier, then ONE thread release-stores the sequence word; the consumer acquire-loads it
+   (agent scope: L2 write-back / invalidate where the workgroups sit on different XCDs) and only then reads the payload. */
+static HD void hv_publish_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+static HD void hv_st_release(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+static HD int  hv_ld_acquire(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+static HD void hv_spin_pause() { __builtin_amdgcn_s_sleep(8); }
+static HD unsigned long long hv_realtime() { return __builtin_amdgcn_s_memrealtime(); }   /* 100 MHz */
 static HD unsigned hv_ldg_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   /* read at the L2: never a stale L1 line */
 #endif
 
@@ -243,6 +257,8 @@ struct alignas(16) HvLds {
     int   c70_len, c70_byp;                                 /* tokens / bypass bins of candidate 70's stream so far */
     u8    nxn_ctx[HEVCE_NCTXP][HV_TL];                      /* context columns of the NxN chain's 35 modes (fresh per 4x4 block) */
     /* control */
+    int cl_seq[2];                                          /* cluster mode: messages sent (chain workgroup) / answered (parent workgroup) per mailbox */
+    int cl_pick, cl_fail;                                   /* parent workgroup: the mailbox to serve next (-1 exit); a hand-off timed out */
     int exact;                                              /* 1: EXACT engines (the reference's bit counts by construction); 0: FAST (see hv_fengine_chunk) */
     int poison;                                             /* FAST: this CTU's decisions may differ from the reference's: 1 = NxN winner, 2 = the writer says so */
     int wr_done;                                            /* CTUs the writer has finished */
@@ -2410,7 +2426,7 @@ static HDN void hv_wr_engine(const HevceImageDesc &im_, int cw, int budget) {
      3. in the time the NxN chain still takes, the prepared candidates of the enclosing CUs ride on.
    The schedule is static and wave-uniform (SGPRs): no lane-dependent control flow may surround the jobs (wave shuffles). */
 #define HV_JOBT(slot, call) call
-static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m, int ctu, int wr_on) {
+static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m, int ctu, int wr_on, int cl) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
     const int wv = hv_uni(wave);
     const int fast = !hv_uni(S.exact);
@@ -2452,6 +2468,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         for (int k = t6; k < HEVCE_NCTXP * HV_TL; k += 384) L0.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[0][k / HV_TL];
         if (t6 < 71) L0.tregs[t6] = S.ent[0];
     }
+    if (hv_uni(cl)) return;                                      /* cluster: the enclosing CUs are the parent workgroup's */
     if (m == 0) {
         /* 16x16: 5 chains (8 modes each) on slots 0..4, 9 single TUs (4 modes each): one each on slots 0..4, four on slot 5 */
         if (w1 < 5) { HV_JOBT(10, hv_job_chain<8>(wave, lane, q, c16, w1, l1, r1)); HV_JOBT(11, hv_job_single<16>(wave, lane, q, c16, w1, l1, r1)); }
@@ -2481,7 +2498,8 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, (m >= 2 ? 2 : 0) | (k16 >= 2 ? 4 : 0), &S.nxn_busy, 6, w1);
 }
 
-static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, HevceRecord *rec, int32_t *dump) {
+static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu);
+static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, HevceRecord *rec, int32_t *dump, int cl) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, n = cu.n;
     HvLds::Level &L = S.lv[cu.lvl];
     HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
@@ -2494,9 +2512,12 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
         /* the split alternative is the state the children left behind  [ref :1409-1410]; it also bounds the pruning */
         if (hv_uni(wave) == 0) hv_job_sse(S, lane, cu);
         BLOCK_SYNC();
-        if (tid == 0) hv_atomic_min(&L.best_cost, hv_rdcost(q, S.split_sse, hv_regs_bits(S.com) - hv_regs_bits(S.ent[cu.lvl])));
-        BLOCK_SYNC();
-        hv_engine_phase(S, im, 1 << cu.lvl, 1);                 /* whatever the slices left over */
+        if (cl) hv_cl_receive(S, im, cu);                        /* cluster: the parent workgroup's best unsplit candidate is the level's only one */
+        else {
+            if (tid == 0) hv_atomic_min(&L.best_cost, hv_rdcost(q, S.split_sse, hv_regs_bits(S.com) - hv_regs_bits(S.ent[cu.lvl])));
+            BLOCK_SYNC();
+            hv_engine_phase(S, im, 1 << cu.lvl, 1);             /* whatever the slices left over */
+        }
     }
     HV_PROF(S, cu.lvl, 2);
     if (dump && tid < HV_TL) {
@@ -2629,6 +2650,191 @@ static HD void hv_snapshot(HvLds &S, int lvl, int tid) {
     if (tid < HEVCE_NCTXP) S.ent_ctx[lvl][tid] = S.com_ctx[tid];
 }
 
+/* --------------------------------------------------------------------------------------------- */
+/* Cluster mode: TWO workgroups per picture.  The chain workgroup (hv_analyse_image) keeps what is serial -- the sixteen 8x8 CUs  */
+/* of a CTU, one after the other, their NxN chains, the commits, the stream writer -- and hands every 16x16 / 32x32 CU to the      */
+/* parent workgroup (hv_parent_worker, on another compute unit) at the moment the CU is ENTERED: its 70 candidates start from the  */
+/* entry snapshot and read only samples outside the CU  [ref :1364-1365, 1420-1424], so they are independent of everything the    */
+/* chain does until the CU's decision, four (sixteen) rounds later.  Back comes the best unsplit candidate; the chain compares it  */
+/* with the split alternative and commits.  Hand-off through HBM (HevceCluster): sequence words with release / acquire at agent   */
+/* scope, every wait bounded (a partner that is not resident must not hang the GPU: the picture is then flagged and the host      */
+/* encodes it again without a cluster).  EXACT CTUs (re-analysis) are done by the chain workgroup alone, as without a cluster.     */
+/* --------------------------------------------------------------------------------------------- */
+#define HV_CL_TIMEOUT 3000000000ull                          /* 30 s of the 100 MHz clock */
+static HD int hv_cl_wait(const int *seq, int want, int *fail) {   /* one thread */
+    const unsigned long long t0 = hv_realtime();
+    for (;;) {
+        if (hv_ld_acquire(seq) == want) return 1;
+        if (hv_realtime() - t0 > HV_CL_TIMEOUT) { *fail = 1; return 0; }
+        hv_spin_pause();
+    }
+}
+/* chain workgroup: the CU of level lvl is entered (S.ent / S.ent_ctx / S.lv[lvl] hold its entry state): tell the parent workgroup.
+   All threads; what the parents read of the picture's reconstruction has been stored by now (fence below). */
+static HD void hv_cl_send(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, int kind) {
+    const int tid = hv_tid(), b = cu.lvl - 1;
+    HevceMsg *m = &im.cluster->msg[b];
+    const HvLds::Level &L = S.lv[cu.lvl];
+    if (tid == 0) {
+        m->kind = kind; m->ctu = ctu; m->y = cu.y; m->x = cu.x; m->n = cu.n;
+        m->range = S.ent[cu.lvl].range; m->nbits = S.ent[cu.lvl].nbits;
+        m->split_inc = L.split_inc; m->ml = L.ml; m->ma = L.ma;
+        m->L = cu.L; m->LB = cu.LB; m->A = cu.A; m->AR = cu.AR;
+    }
+    if (tid < HEVCE_NCTXP) m->ctx[tid] = S.ent_ctx[cu.lvl][tid];
+    hv_publish_fence();
+    BLOCK_SYNC();
+    if (tid == 0) { const int s = S.cl_seq[b] + 1; S.cl_seq[b] = s; hv_st_release(&m->seq, s); }
+}
+/* chain workgroup, at the CU's decision: wait for the answer and make its candidate the only one alive of the level.  All threads. */
+static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu) {
+    const int tid = hv_tid(), b = cu.lvl - 1;
+    HvLds::Level &L = S.lv[cu.lvl];
+    const HevceRes *r = &im.cluster->res[b];
+    if (tid == 0) { if (!hv_cl_wait(&r->seq, S.cl_seq[b], &S.cl_fail)) im.cluster->error = 1; }
+    BLOCK_SYNC();
+    const int w = hv_min(hv_max(r->winner, 0), 69);
+    if (tid < HV_TL) L.tdead[tid] = tid != w;
+    if (tid == 0) { L.tcost[w] = r->cost; L.tsse[w] = r->sse; L.tregs[w] = S.ent[cu.lvl]; L.tregs[w].range = r->range; L.tregs[w].nbits = r->nbits; L.tnlog[w] = 0; }
+    if (tid < HEVCE_NCTXP) L.tctx[tid][w] = r->ctx[tid];
+    BLOCK_SYNC();
+}
+/* the samples of a CU that has just been decided go to the picture's reconstruction at once (the parents of the NEXT CUs read them there) */
+static HD void hv_cl_store_rcon(HvLds &S, const HevceImageDesc &im, const HvCu cu, int y0, int x0) {
+    for (int p = hv_tid(); p < cu.n * cu.n; p += HV_NTHREADS) {
+        const int yy = cu.y + p / cu.n, xx = cu.x + p % cu.n;
+        im.rcon[(size_t)(y0 + yy) * im.W + x0 + xx] = S.rec[yy + 1][xx + HV_RX];
+    }
+}
+
+/* parent workgroup: one stage of a CU's evaluation.  stage 0: block jobs (step 2 / step 3 of the reference's search for this CU,
+   [ref :1420-1432, 1455-1468]), 1: context columns + binarisation, 2: the candidates' engines to their end, arg-min, answer. */
+static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, int stage) {
+    const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, wv = hv_uni(wave);
+    HvLds::Level &L = S.lv[cu.lvl];
+    HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
+    HvGLev glev = (HvGLev)scr;
+    HvGRec grec = (HvGRec)(scr + HV_TL * 1024 * 2);
+    if (stage == 0) {
+        if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = 0; L.tlen[tid] = 0; }
+        if (tid == 0) L.best_cost = HV_I32MAX;
+        if (cu.n == 16) {
+            /* 5 chains (8 modes each) + 9 single blocks (4 modes each) over 8 wavefronts */
+            if (wv < 5) hv_job_chain<8>(wave, lane, q, cu, wv, glev, grec);
+            for (int j = (wv < 5 ? wv + 3 : wv - 5); j < 9; j += 8) hv_job_single<16>(wave, lane, q, cu, j, glev, grec);
+        } else {
+            /* 9 chains (4 modes each, the long ones) + 18 single blocks (2 modes each): wavefront 0 takes chains 0 and 8, the others a
+               chain and two or three single blocks each */
+            hv_job_chain<16>(wave, lane, q, cu, wv, glev, grec);
+            if (wv == 0) hv_job_chain<16>(wave, lane, q, cu, 8, glev, grec);
+            else for (int j = wv - 1; j < 18; j += 7) hv_job_single<32>(wave, lane, q, cu, j, glev, grec);
+        }
+    } else if (stage == 1) {
+        hv_level_contexts(S, im, cu);                            /* ends with a barrier */
+        const int tb = 9 * wv, tc = hv_min(9, 70 - tb);
+        hv_bin_own<true>(scr, cu, tb, tc);
+    } else {
+        hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, 1 << cu.lvl, nullptr, 8, wave);
+        BLOCK_SYNC();
+        if (wv == 0) {                                           /* arg-min, the later candidate wins ties  [ref :1440, 1476] */
+            int bc = HV_I32MAX, bi = -2;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int t = lane + 64 * u;
+                const bool ok = t < 70 && !L.tdead[hv_min(t, HV_TL - 1)];
+                const int c = L.tcost[hv_min(t, HV_TL - 1)];
+                const bool take = ok && (bi == -2 || c < bc || (c == bc && t > bi));
+                bc = take ? c : bc; bi = take ? t : bi;
+            }
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                const int oc = hv_shfl_xor(bc, sft), oi = hv_shfl_xor(bi, sft);
+                const bool take = oi != -2 && (bi == -2 || oc < bc || (oc == bc && oi > bi));
+                bc = take ? oc : bc; bi = take ? oi : bi;
+            }
+            if (lane == 0) S.winner = bi;
+        }
+        BLOCK_SYNC();
+        const int w = hv_min(hv_max(S.winner, 0), 69);
+        HevceRes *r = &im.cluster->res[cu.lvl - 1];
+        if (tid == 0) { r->cost = L.tcost[w]; r->winner = w; r->sse = L.tsse[w]; r->range = L.tregs[w].range; r->nbits = L.tregs[w].nbits - L.tnlog[w]; }
+        if (tid < HEVCE_NCTXP) r->ctx[tid] = L.tctx[tid][w];
+        hv_publish_fence();                                      /* the answer, and the winner's levels / samples in the level scratch */
+        BLOCK_SYNC();
+        if (tid == 0) { const int sq = S.cl_seq[cu.lvl - 1] + 1; S.cl_seq[cu.lvl - 1] = sq; hv_st_release(&r->seq, sq); }
+    }
+    BLOCK_SYNC();
+}
+/* parent workgroup: a message has arrived on mailbox b: the CU, its entry state, the CTU's source samples and the
+   reconstruction around it (the CU's candidates read samples outside the CU only) */
+static HD HvCu hv_pw_accept(HvLds &S, const HevceImageDesc &im, int b) {
+    const int tid = hv_tid();
+    const HevceMsg *m = &im.cluster->msg[b];
+    const int lvl = b + 1, ncx = im.W >> 5, ctu = m->ctu;
+    const int y0 = (ctu / ncx) * 32, x0 = (ctu % ncx) * 32;
+    HvCu cu = { m->y, m->x, m->n, m->n == 16 ? 4 : 5, lvl, m->L, m->LB, m->A, m->AR };
+    HvLds::Level &L = S.lv[lvl];
+    if (tid == 0) {
+        S.ent[lvl].range = m->range; S.ent[lvl].low = 0; S.ent[lvl].nbits = m->nbits; S.ent[lvl].nbytes = 0; S.ent[lvl].bufbyte = 0; S.ent[lvl].zeros = 0; S.ent[lvl].nout = 0; S.ent[lvl].pad = 0;
+        L.split_inc = m->split_inc; L.ml = m->ml; L.ma = m->ma;
+    }
+    if (tid < HEVCE_NCTXP) S.ent_ctx[lvl][tid] = m->ctx[tid];
+    for (int p = tid; p < 1024; p += HV_NTHREADS) {                 /* source samples, edge-replicated  [ref :1620-1622] */
+        const int yy = hv_min(y0 + (p >> 5), im.src_h - 1), xx = hv_min(x0 + (p & 31), im.src_w - 1);
+        S.org[p >> 5][p & 31] = im.img[(size_t)yy * (size_t)im.src_stride + xx];
+    }
+    for (int p = tid; p < 33 * 65; p += HV_NTHREADS) {              /* rows y0-1 .. y0+31, columns x0-1 .. x0+63 of the reconstruction so far */
+        const int r = p / 65, c = p % 65;
+        const int yy = hv_min(hv_max(y0 - 1 + r, 0), im.H - 1), xx = hv_min(hv_max(x0 - 1 + c, 0), im.W - 1);
+        S.rec[r][HV_RX - 1 + c] = im.rcon[(size_t)yy * im.W + xx];
+    }
+    BLOCK_SYNC();
+    return cu;
+}
+/* The parent workgroup of a picture (cluster mode, second workgroup): it answers the chain workgroup's messages until told to
+   exit.  16x16 CUs are answered at once (the chain needs them four rounds later); the 32x32 CU of a CTU, whose answer is due
+   at the end of the CTU, is worked on stage by stage in between. */
+static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im) {
+    const int tid = hv_tid(), q = im.qpd6;
+    if (tid == 0) { S.trace = nullptr; S.qlut = im.qlut; }
+    BLOCK_SYNC();
+    hv_init_tables(S, q, tid);
+    hv_set_mode(S, 0, tid);
+    if (tid == 0) { S.cl_seq[0] = S.cl_seq[1] = 0; S.cl_fail = 0; S.cl_pick = 0; }
+    BLOCK_SYNC();
+    hv_init_sigtab(S, tid);
+    BLOCK_SYNC();
+    HevceCluster *C = im.cluster;
+    int stage32 = -1;                                            /* -1: no 32x32 CU in progress */
+    HvCu c32 = { 0, 0, 32, 5, 2, 0, 0, 0, 0 };
+    for (;;) {
+        if (tid == 0) {
+            const unsigned long long t0 = hv_realtime();
+            int pick = 0;
+            for (;;) {
+                if (hv_ld_acquire(&C->msg[0].seq) == S.cl_seq[0] + 1) { pick = 1; break; }              /* a 16x16 CU (or the exit message): first */
+                if (stage32 >= 0) { pick = 2; break; }                                                   /* the 32x32 CU in progress */
+                if (hv_ld_acquire(&C->msg[1].seq) == S.cl_seq[1] + 1) { pick = 3; break; }              /* a new 32x32 CU */
+                if (hv_realtime() - t0 > HV_CL_TIMEOUT) { pick = -1; C->error = 2; break; }
+                hv_spin_pause();
+            }
+            S.cl_pick = pick;
+        }
+        BLOCK_SYNC();
+        const int pick = hv_uni(S.cl_pick);
+        BLOCK_SYNC();
+        if (pick < 0) break;
+        if (pick == 1) {
+            if (C->msg[0].kind == 2) break;
+            const HvCu cu = hv_pw_accept(S, im, 0);
+            for (int st = 0; st < 3; st++) hv_pw_stage(S, im, cu, st);
+        } else {
+            if (pick == 3) { c32 = hv_pw_accept(S, im, 1); stage32 = 0; }   /* a 16x16 CU served in between reloads the same CTU's samples: harmless */
+            hv_pw_stage(S, im, c32, stage32);
+            stage32 = stage32 == 2 ? -1 : stage32 + 1;
+        }
+    }
+}
+
 /* the writer does a whole CTU in one go (wavefront 4; the others wait at the caller's barrier) */
 static HD void hv_wr_whole(HvLds &S, const HevceImageDesc &im, int cw) {
     if ((hv_tid() >> 6) == 4) {
@@ -2677,7 +2883,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int force_exact = (im.flags & 1) || !im.payload;      /* without the writer nothing vouches for the FAST decisions */
     const int pk_nxn = (im.flags >> 8) & 0xff, pk_wr = (im.flags >> 16) & 0xff;
     hv_set_mode(S, force_exact, tid);
-    if (tid == 0) { S.poison = 0; S.wr_done = 0; }
+    if (tid == 0) { S.poison = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = 0; S.cl_fail = 0; }
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
     BLOCK_SYNC();
@@ -2686,6 +2892,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     for (;;) {
         const int exact = hv_uni(S.exact);
         const int tail = ctu == nctu;                            /* past the last CTU: only the writer has work left */
+        const int cl = im.cluster != nullptr && !exact;          /* the parent workgroup evaluates this CTU's 16x16 / 32x32 CUs */
         const int wr_on = im.payload && ctu > 0 && hv_uni(S.wr_done) < ctu;   /* the writer does CTU ctu - 1 during this round */
         const int y0 = (ctu / ncx) * 32, x0 = (ctu % ncx) * 32;
         if (wr_on && tid == 4 * 64) { S.wsnap = S.wr; S.wr_epb = 0; }
@@ -2739,6 +2946,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     hv_snapshot(S, 2, tid);
                     hv_level_begin(S, c32);
                     BLOCK_SYNC();
+                    if (cl) hv_cl_send(S, im, c32, ctu, 1);
                     if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + S.lv[2].split_inc, 1);
                     BLOCK_SYNC();
                 }
@@ -2746,6 +2954,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     hv_snapshot(S, 1, tid);
                     hv_level_begin(S, c16);
                     BLOCK_SYNC();
+                    if (cl) hv_cl_send(S, im, c16, ctu, 1);
                     if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + S.lv[1].split_inc, 1);
                     BLOCK_SYNC();
                 }
@@ -2757,7 +2966,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
 #ifdef HEVCE_PROF_JDUR
                     const unsigned long long j0_ = __builtin_amdgcn_s_memtime();
 #endif
-                    hv_jobs_phase(S, im, cu, c16, c32, k, m, ctu, wr_on);
+                    hv_jobs_phase(S, im, cu, c16, c32, k, m, ctu, wr_on, cl);
 #ifdef HEVCE_PROF_JDUR
                     if (tid == HEVCE_PROF_JDUR * 64) S.prof2[16 + k * 4 + m] += __builtin_amdgcn_s_memtime() - j0_;   /* that wavefront's jobs phase, riders included */
 #endif
@@ -2769,11 +2978,14 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     if (tid == 0) S.prof2[16 + k * 4 + m] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
                     HV_PROF(S, 0, 0);
-                    if (m == 0) hv_level_contexts(S, im, c16);
-                    if (k == 1 && m == 2) hv_level_contexts(S, im, c32);     /* its jobs ran in five phases up to this one */
-                    hv_engine_phase(S, im, 1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0), 0);
+                    if (!cl) {
+                        if (m == 0) hv_level_contexts(S, im, c16);
+                        if (k == 1 && m == 2) hv_level_contexts(S, im, c32);     /* its jobs ran in five phases up to this one */
+                    }
+                    hv_engine_phase(S, im, cl ? 1 : (1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0)), 0);
                 }
-                hv_decide_cu(S, im, cu, ctu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr);
+                hv_decide_cu(S, im, cu, ctu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr, cl);
+                if (cl && cu.n == 16) hv_cl_store_rcon(S, im, cu, y0, x0);   /* the next 16x16 CU's parents predict from these samples */
             }
 
         }
@@ -2835,7 +3047,13 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
         }
         ctu++;
     }
-    if (im.stats && tid == 0) { im.stats[0] = n_redo; im.stats[1] = n_bad; }
+    if (im.cluster) {                                            /* the parent workgroup may go home */
+        const HvCu none = { 0, 0, 16, 4, 1, 0, 0, 0, 0 };
+        BLOCK_SYNC();
+        hv_cl_send(S, im, none, nctu, 2);
+    }
+    if (im.stats && tid == 0) { im.stats[0] = n_redo; im.stats[1] = n_bad + S.cl_fail; }
+    if (S.cl_fail && im.payload_len && tid == 0) *im.payload_len = -1;   /* a hand-off timed out: the host encodes the picture again without a cluster */
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     if (im.trace && tid < 24) { ((unsigned long long *)im.trace)[tid] = (&S.prof[0][0])[tid]; }
     if (im.trace && tid < 32) { ((unsigned long long *)im.trace)[24 + tid] = S.prof2[tid]; }

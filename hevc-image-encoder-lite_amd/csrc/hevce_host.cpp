@@ -30,7 +30,7 @@ extern "C" int hevce_launch_test_tu(const unsigned char *org, const unsigned cha
                                     short *lev, unsigned char *rec, int *info, const unsigned short *qlut, hipStream_t stream);
 extern "C" int hevce_launch_test_chain(const unsigned char *org, const unsigned char *nbr, int n, int q, int aL, int aLB, int aA, int aAR,
                                        unsigned char *scratch, int *info, const unsigned short *qlut, hipStream_t stream);
-extern "C" int hevce_launch_analyse(const HevceImageDesc *d_images, int n, hipStream_t stream);   /* hevce_kernel.hip */
+extern "C" int hevce_launch_analyse(const HevceImageDesc *d_images, int n, int cluster, hipStream_t stream);   /* hevce_kernel.hip */
 
 namespace {
 
@@ -95,7 +95,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 struct Image {
     int h0, w0, H, W, q, nctu;
     size_t off_img, off_rcon, off_rec, off_state, off_scratch;   /* into the device slab */
-    size_t off_payload, off_plen, off_stats, off_wrtok;                     /* the kernel's stream writer: slice data, its length; re-analysis statistics */
+    size_t off_payload, off_plen, off_stats, off_wrtok, off_cluster;                     /* the kernel's stream writer: slice data, its length; re-analysis statistics */
     size_t hoff_rec, hoff_state, hoff_plen;                      /* into the pinned host slab */
     const void *ext_img = nullptr;
     long ext_stride = 0;                                         /* row stride of ext_img (0: w0) */
@@ -129,6 +129,7 @@ struct hevce_job {
     uint8_t *h_streams = nullptr; size_t h_streams_bytes = 0;   /* pinned: header + slice data of every picture, back to back; grows on demand */
     bool device_emit = true;         /* the kernel emits the slice data itself; HEVCE_HOST_WRITER=1: replay the records on the host instead */
     int flags = 0;                   /* HevceImageDesc.flags (tests: HEVCE_FLAGS) */
+    bool cluster = false;            /* two workgroups per picture (hevce_device.h): when both fit the device side by side */
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     float kernel_ms = 0, d2h_ms = 0, writer_ms = 0;
@@ -169,6 +170,7 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
         m.off_plen = d;    d = align256(d + 4);
         m.off_stats = d;   d = align256(d + 8);
         m.off_wrtok = d;   d = align256(d + HEVCE_WRTOK_BYTES);
+        m.off_cluster = d; d = align256(d + sizeof(HevceCluster));
         m.hoff_rec = h;    h = align256(h + size_t(m.nctu) * HEVCE_REC_BYTES);
         m.hoff_state = h;  h = align256(h + size_t(m.nctu) * 32);
         m.hoff_plen = h;   h = align256(h + 4);
@@ -183,6 +185,15 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
     j->stream = j->own_stream;
     j->device_emit = getenv("HEVCE_HOST_WRITER") == nullptr;
     if (const char *e = getenv("HEVCE_FLAGS")) j->flags = (int)strtol(e, nullptr, 0);
+    {
+        /* Cluster mode needs both workgroups of every picture resident at the same time (they wait for each other): one workgroup
+           per compute unit (its LDS), so at most CUs / 2 pictures; HEVCE_CLUSTER=0 / 1 overrides the choice (1 is still bounded) */
+        hipDeviceProp_t prop;
+        int cus = 0;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+        j->cluster = j->device_emit && cus >= 2 && 2 * n <= cus;
+        if (const char *e = getenv("HEVCE_CLUSTER")) j->cluster = j->cluster && atoi(e) != 0;
+    }
     if (getenv("HEVCE_DUMP")) {
         for (int i = 0; i < n; i++) j->dump_ints += size_t(j->im[i].nctu) * 21 * HEVCE_TRIALS * 16;
         if (hipMalloc((void **)&j->d_dump, j->dump_ints * 4) != hipSuccess) j->d_dump = nullptr;
@@ -292,14 +303,17 @@ int hevce_job_launch(hevce_job *j) {
             d.payload = j->device_emit ? j->d_slab + m.off_payload : nullptr;
             d.stats = (int32_t *)(j->d_slab + m.off_stats);
             d.wr_tok = j->d_slab + m.off_wrtok;
+            d.cluster = (j->cluster && !(j->flags & 2)) ? (HevceCluster *)(j->d_slab + m.off_cluster) : nullptr;
             d.flags = j->flags; d.pad_ = 0;
             d.payload_len = j->device_emit ? (int32_t *)(j->d_slab + m.off_plen) : nullptr;
         }
         HIPCHK(hipMemcpyAsync(j->d_desc, j->h_desc.data(), sizeof(HevceImageDesc) * j->n, hipMemcpyHostToDevice, j->stream));
         j->desc_dirty = false;
     }
+    const bool cluster = j->cluster && !(j->flags & 2);
+    if (cluster) for (int i = 0; i < j->n; i++) HIPCHK(hipMemsetAsync(j->d_slab + j->im[i].off_cluster, 0, sizeof(HevceCluster), j->stream));   /* sequence words start at 0 */
     HIPCHK(hipEventRecord(j->ev0, j->stream));
-    if (hevce_launch_analyse(j->d_desc, j->n, j->stream) != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (hevce_launch_analyse(j->d_desc, j->n, cluster ? 1 : 0, j->stream) != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     HIPCHK(hipEventRecord(j->ev1, j->stream));
     /* what the host needs in every case: the length of each picture's slice data.  The decision records and per-CTU coder
        registers (2176 + 32 bytes per CTU) only travel when somebody wants them: the host-writer mode, hevce_job_download_records */
@@ -333,6 +347,14 @@ int hevce_job_finish(hevce_job *j) {
         for (int i = 0; i < j->n; i++) {
             Image &m = j->im[i];
             const int plen = *(const int32_t *)(j->h_slab + m.hoff_plen);
+            if (plen == -1 && j->cluster && !(j->flags & 2)) {
+                /* a hand-off between a picture's two workgroups timed out (they were not resident side by side): once more, one
+                   workgroup per picture */
+                fprintf(stderr, "hevce_mi355x: cluster hand-off timed out (image %d); encoding again without clusters\n", i);
+                j->cluster = false; j->desc_dirty = true;
+                if (hevce_job_launch(j) != 0) return -1;
+                return hevce_job_finish(j);
+            }
             if (plen <= 0 || size_t(plen) > size_t(m.nctu) * 3200 + 64) return fail("image %d: the device emitted %d bytes", i, plen);
             need += 128 + size_t(plen);
         }

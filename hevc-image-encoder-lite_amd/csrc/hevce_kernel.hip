@@ -4,16 +4,18 @@
 #include "hevce_device.h"
 
 extern "C" __global__ void __launch_bounds__(HV_NTHREADS, 2)
-hevce_analyse_kernel(const HevceImageDesc *__restrict__ images, int nimages) {
-    const int b = blockIdx.x;
-    if (b >= nimages) return;
-    const HevceImageDesc im = images[b];
-    hv_analyse_image(HV_S, im);
+hevce_analyse_kernel(const HevceImageDesc *__restrict__ images, int nimages, int cluster) {
+    /* cluster mode: two workgroups per picture -- 2 i walks picture i's chain of decisions, 2 i + 1 evaluates its 16x16 / 32x32 CUs */
+    const int b = blockIdx.x, pic = cluster ? b >> 1 : b;
+    if (pic >= nimages) return;
+    const HevceImageDesc im = images[pic];
+    if (cluster && (b & 1)) hv_parent_worker(HV_S, im);
+    else hv_analyse_image(HV_S, im);
 }
 
-/* host-side launcher used by hevce_host.cpp: grid = images of the batch */
-extern "C" int hevce_launch_analyse(const HevceImageDesc *d_images, int n, hipStream_t stream) {
-    hipLaunchKernelGGL(hevce_analyse_kernel, dim3((unsigned)n), dim3(HV_NTHREADS), 0, stream, d_images, n);
+/* host-side launcher used by hevce_host.cpp: grid = images of the batch (twice that in cluster mode) */
+extern "C" int hevce_launch_analyse(const HevceImageDesc *d_images, int n, int cluster, hipStream_t stream) {
+    hipLaunchKernelGGL(hevce_analyse_kernel, dim3((unsigned)(cluster ? 2 * n : n)), dim3(HV_NTHREADS), 0, stream, d_images, n, cluster);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

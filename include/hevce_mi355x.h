@@ -84,8 +84,9 @@ int  hevce_job_timings(hevce_job *job, float *kernel_ms, float *d2h_ms, float *w
 
 /* The kernel analyses with range-only ("FAST") trial coders and re-analyses with the exact ones the few CTUs whose bit counts
    an emulation-prevention byte could have changed; stats: out2[0] = CTUs of image i analysed twice in the last
-   run, out2[1] = coder consistency failures (always 0).  flags (tests): bit 0 = exact coders throughout, bits 8-15 / 16-23 =
-   force a re-analysis every k-th CTU through either detection path. */
+   run, out2[1] = coder consistency failures (always 0).  flags (tests): bit 0 = exact coders throughout, bit 1 = one workgroup
+   per picture even when two would fit (no cluster mode), bits 8-15 / 16-23 = force a re-analysis every k-th CTU through either
+   detection path. */
 int  hevce_job_set_flags(hevce_job *job, int flags);
 int  hevce_job_stats(hevce_job *job, int i, int *out2);
 

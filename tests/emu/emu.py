@@ -29,7 +29,7 @@ def lib():
     return _lib
 
 
-def analyse(img, q, want_dump=False, flags=0):
+def analyse(img, q, want_dump=False, flags=0, cluster=0):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
     H, W = (min(h, 8192) + 31) // 32 * 32, (min(w, 8192) + 31) // 32 * 32
@@ -43,8 +43,8 @@ def analyse(img, q, want_dump=False, flags=0):
     stats = np.zeros(2, np.int32)
     rc = lib().emu_analyse(img.ctypes.data_as(_u8p), h, w, q, rcon.ctypes.data_as(_u8p), rec.ctypes.data_as(_u8p),
                            st.ctypes.data_as(C.POINTER(C.c_int32)), dump.ctypes.data_as(C.POINTER(C.c_int32)) if want_dump else None,
-                           payload.ctypes.data_as(_u8p), C.byref(plen), flags, stats.ctypes.data_as(C.POINTER(C.c_int32)))
-    assert rc == 0, "emulator deadlock"
+                           payload.ctypes.data_as(_u8p), C.byref(plen), flags, stats.ctypes.data_as(C.POINTER(C.c_int32)), cluster)
+    assert rc == 0, "emulator deadlock" if rc == -1 else "cluster hand-off failed"
     analyse.stats = stats
     analyse.payload = bytes(payload[:max(plen.value, 0)])          # the slice data the device emitted itself
     return (rec, rcon, st, dump) if want_dump else (rec, rcon, st)

@@ -6,16 +6,16 @@
 
 int emu_cur = 0;
 HvLds *emu_lds_ptr = nullptr;
-int emu_stage[8][64];
+int emu_stage[16][64];
 
 namespace {
-enum { NT = HV_NTHREADS, STACK = 256 * 1024 };
+enum { NT = HV_NTHREADS, NWG = 2, STACK = 256 * 1024 };
 enum State { RUN, WAIT_WAVE, WAIT_BLOCK, DONE };
 struct Fiber { void *sp; State st; char *stack; };
-Fiber fib[NT];
+Fiber fib[NWG * NT];
 void *sched_sp;
-int wave_wait[8], block_wait, ndone;
-HvLds *g_lds;
+int wave_wait[NWG * 8], block_wait[NWG], ndone;
+HvLds *g_lds[NWG];
 const HevceImageDesc *g_im;
 
 extern "C" void emu_switch(void **save_sp, void *new_sp);
@@ -43,7 +43,8 @@ emu_switch:
 void yield_to_sched() { emu_switch(&fib[emu_cur].sp, sched_sp); }
 
 void fiber_entry() {
-    hv_analyse_image(*g_lds, *g_im);
+    if (emu_cur >= NT) hv_parent_worker(*g_lds[1], *g_im);       /* cluster mode: the second workgroup */
+    else hv_analyse_image(*g_lds[0], *g_im);
     fib[emu_cur].st = DONE;
     ndone++;
     yield_to_sched();
@@ -59,13 +60,13 @@ void emu_wave_sync(void) {
 void emu_yield(void) { yield_to_sched(); }                  /* stays runnable */
 void emu_block_sync(void) {
     fib[emu_cur].st = WAIT_BLOCK;
-    block_wait++;
+    block_wait[emu_cur / NT]++;
     yield_to_sched();
 }
 
 extern "C" __attribute__((visibility("default")))
 int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, uint8_t *records, int32_t *ctu_state, int32_t *dump,
-                uint8_t *payload, int32_t *payload_len, int flags, int32_t *stats) {
+                uint8_t *payload, int32_t *payload_len, int flags, int32_t *stats, int cluster) {
     HevceImageDesc im;
     memset(&im, 0, sizeof im);
     im.img = img; im.rcon = rcon; im.records = records; im.ctu_state = ctu_state;
@@ -85,11 +86,17 @@ int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, 
     im.W = ((src_w < HEVCE_MAXDIM ? src_w : HEVCE_MAXDIM) + 31) / 32 * 32;
     std::vector<uint8_t> scratch(HEVCE_SCRATCH_BYTES, 0xCD);
     im.scratch = scratch.data();
-    HvLds *lds = (HvLds *)aligned_alloc(64, (sizeof(HvLds) + 63) / 64 * 64);
-    memset(lds, 0xAB, sizeof(HvLds));                     /* LDS is not zero-initialised on the GPU either */
-    g_lds = lds; g_im = &im; emu_lds_ptr = lds;
-    memset(wave_wait, 0, sizeof wave_wait); block_wait = 0; ndone = 0;
-    for (int i = 0; i < NT; i++) {
+    const int nwg = cluster ? 2 : 1, nfib = nwg * NT;
+    static HevceCluster cl;
+    memset(&cl, 0, sizeof cl);
+    im.cluster = cluster ? &cl : nullptr;
+    for (int g = 0; g < nwg; g++) {
+        g_lds[g] = (HvLds *)aligned_alloc(64, (sizeof(HvLds) + 63) / 64 * 64);
+        memset(g_lds[g], 0xAB, sizeof(HvLds));                /* LDS is not zero-initialised on the GPU either */
+    }
+    g_im = &im;
+    memset(wave_wait, 0, sizeof wave_wait); memset(block_wait, 0, sizeof block_wait); ndone = 0;
+    for (int i = 0; i < nfib; i++) {
         fib[i].stack = (char *)aligned_alloc(64, STACK);
         void **sp = (void **)(fib[i].stack + STACK - 64 - 8);   /* at fiber_entry's first instruction rsp must be 8 mod 16 */
         *--sp = (void *)fiber_entry;                      /* return address for emu_switch's ret */
@@ -97,35 +104,38 @@ int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, 
         fib[i].sp = sp; fib[i].st = RUN;
     }
     int rc = 0;
-    while (ndone < NT) {
+    while (ndone < nfib) {
         bool progress = false;
-        for (int i = 0; i < NT; i++) {
+        for (int i = 0; i < nfib; i++) {
             if (fib[i].st != RUN) continue;
             emu_cur = i;
+            emu_lds_ptr = g_lds[i / NT];
             emu_switch(&sched_sp, fib[i].sp);
             progress = true;
         }
-        for (int w = 0; w < 8; w++)
+        for (int w = 0; w < nwg * 8; w++)
             if (wave_wait[w] == 64) {
                 wave_wait[w] = 0;
                 for (int l = 0; l < 64; l++) fib[w * 64 + l].st = RUN;
                 progress = true;
             }
-        if (block_wait == NT) {
-            block_wait = 0;
-            for (int i = 0; i < NT; i++) fib[i].st = RUN;
-            progress = true;
-        }
+        for (int g = 0; g < nwg; g++)
+            if (block_wait[g] == NT) {
+                block_wait[g] = 0;
+                for (int i = 0; i < NT; i++) fib[g * NT + i].st = RUN;
+                progress = true;
+            }
         if (!progress) {
-            fprintf(stderr, "emu: deadlock (divergent synchronisation): block_wait=%d done=%d waves:", block_wait, ndone);
-            for (int w = 0; w < 8; w++) fprintf(stderr, " %d", wave_wait[w]);
+            fprintf(stderr, "emu: deadlock (divergent synchronisation): block_wait=%d %d done=%d waves:", block_wait[0], block_wait[1], ndone);
+            for (int w = 0; w < nwg * 8; w++) fprintf(stderr, " %d", wave_wait[w]);
             fprintf(stderr, "\n");
             rc = -1;
             break;
         }
     }
-    for (int i = 0; i < NT; i++) free(fib[i].stack);
-    free(lds);
+    for (int i = 0; i < nfib; i++) free(fib[i].stack);
+    for (int g = 0; g < nwg; g++) free(g_lds[g]);
+    if (cluster && cl.error) rc = -2;
     return rc;
 }
 extern "C" __attribute__((visibility("default"))) int emu_lds_bytes(void) { return (int)sizeof(HvLds); }

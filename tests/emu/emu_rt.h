@@ -17,13 +17,13 @@
 
 void emu_wave_sync(void);
 void emu_block_sync(void);
-extern int  emu_cur;                 /* running fiber = thread id */
-extern int  emu_stage[8][64];        /* shuffle staging, per wave */
+extern int  emu_cur;                 /* running fiber = workgroup * 512 + thread id */
+extern int  emu_stage[16][64];       /* shuffle staging, per wave (two workgroups) */
 
 #define WAVE_SYNC()  emu_wave_sync()
 #define BLOCK_SYNC() emu_block_sync()
 
-static inline int hv_tid() { return emu_cur; }
+static inline int hv_tid() { return emu_cur & 511; }
 static inline int hv_shfl_xor(int v, int m) {
     const int w = emu_cur >> 6, l = emu_cur & 63;
     emu_stage[w][l] = v;

@@ -49,9 +49,10 @@ def test_records_and_states_match_oracle(hevce, orc):
             assert job.stream(0) == orc.write_stream(orec, orcon.shape[0], orcon.shape[1], q)
 
 
-@pytest.mark.parametrize("flags", [1, 2 << 8, 3 << 16, (1 << 8) | (1 << 16), (5 << 8) | (7 << 16)],
-                         ids=["exact", "nxn2", "wr3", "every-ctu-both", "nxn5-wr7"])
-def test_fast_analysis_and_exact_reanalysis_paths(hevce, orc, flags):
+@pytest.mark.parametrize("single", [0, 2], ids=["cluster", "one-workgroup"])
+@pytest.mark.parametrize("flags", [0, 1, 2 << 8, 3 << 16, (1 << 8) | (1 << 16), (5 << 8) | (7 << 16)],
+                         ids=["fast", "exact", "nxn2", "wr3", "every-ctu-both", "nxn5-wr7"])
+def test_fast_analysis_and_exact_reanalysis_paths(hevce, orc, flags, single):
     """The kernel decides with range-only trial coders and re-analyses poisoned CTUs with the exact ones.  The test
     hooks poison CTUs through both detection paths; streams, reconstruction, records and coder registers stay the oracle's and
     the writer's coder never disagrees with the analysis' (stats[1] == 0)."""
@@ -59,7 +60,7 @@ def test_fast_analysis_and_exact_reanalysis_paths(hevce, orc, flags):
     imgs = [wl.gen_g2(96, 160, 16, seed=4242), wl.gen_g2(70, 100, 4, seed=7), (np.random.RandomState(3).randint(0, 2, (64, 96)) * 255).astype(np.uint8)]
     qs = [2, 0, 4]
     with hevce.Job([im.shape for im in imgs], qs) as job:
-        job.set_flags(flags)
+        job.set_flags(flags | single)                            # bit 1: one workgroup per picture; otherwise two (cluster mode) as they fit the device
         for i, im in enumerate(imgs):
             job.upload(i, im)
         job.run()
@@ -70,7 +71,7 @@ def test_fast_analysis_and_exact_reanalysis_paths(hevce, orc, flags):
             assert job.stream(i) == s and np.array_equal(job.rcon(i), r), i
             assert np.array_equal(rec, orec) and np.array_equal(st, ost), i
             redo, bad = job.stats(i)
-            assert bad == 0 and (redo > 0) == (flags != 1), (i, redo, bad)
+            assert bad == 0 and (redo > 0) == (flags > 1), (i, redo, bad)
 
 
 def test_batch_of_ragged_images(hevce, orc):
