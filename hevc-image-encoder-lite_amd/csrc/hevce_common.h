@@ -52,7 +52,7 @@ typedef struct HevceCoderRegs {
 } HevceCoderRegs;
 
 /* Cluster mode (two workgroups per picture, hevce_device.h hv_parent_worker): mailboxes in HBM between the workgroup that walks
-   the picture's chain of 8x8 decisions and the one that evaluates the enclosing 16x16 / 32x32 CUs for it.  index = CU level - 1. */
+   the picture's chain of 8x8 decisions and the ones that evaluate candidates for it.  index = (CU level + 2) % 3: 16x16, 32x32, 8x8. */
 typedef struct HevceMsg {      /* analysis workgroup -> parent workgroup: "evaluate this CU from this entry state" */
     int32_t seq;               /* message number on this mailbox, written last (release); 0 = none yet */
     int32_t kind;              /* 1 = evaluate, 2 = exit */
@@ -70,7 +70,7 @@ typedef struct HevceRes {      /* parent workgroup -> analysis workgroup: the be
     int32_t pad_[2];
     uint8_t ctx[104];          /* contexts after it */
 } HevceRes;
-typedef struct HevceCluster { HevceMsg msg[2]; HevceRes res[2]; int32_t error; int32_t pad_[3]; } HevceCluster;
+typedef struct HevceCluster { HevceMsg msg[3]; HevceRes res[3]; int32_t error; int32_t size; int32_t pad_[2]; } HevceCluster;   /* mailboxes: 16x16, 32x32, 8x8 (4 workgroups only) */
 
 /* one image of a batch, as the kernel sees it (all pointers are device pointers) */
 typedef struct HevceImageDesc {

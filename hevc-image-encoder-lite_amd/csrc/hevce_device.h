@@ -257,7 +257,7 @@ struct alignas(16) HvLds {
     int   c70_len, c70_byp;                                 /* tokens / bypass bins of candidate 70's stream so far */
     u8    nxn_ctx[HEVCE_NCTXP][HV_TL];                      /* context columns of the NxN chain's 35 modes (fresh per 4x4 block) */
     /* control */
-    int cl_seq[2];                                          /* cluster mode: messages sent (chain workgroup) / answered (parent workgroup) per mailbox */
+    int cl_seq[3];                                          /* cluster mode: messages sent (chain workgroup) / answered (parent workgroup) per mailbox */
     int cl_pick, cl_fail;                                   /* parent workgroup: the mailbox to serve next (-1 exit); a hand-off timed out */
     int exact;                                              /* 1: EXACT engines (the reference's bit counts by construction); 0: FAST (see hv_fengine_chunk) */
     int poison;                                             /* FAST: this CTU's decisions may differ from the reference's: 1 = NxN winner, 2 = the writer says so */
@@ -2449,6 +2449,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         }
         return;
     }
+    if (hv_uni(cl) == 2) return;                                 /* cluster of 4: this CU's block jobs and candidates 0..69 are another workgroup's */
     const int w1 = wv < 4 ? wv - 1 : wv - 2;                     /* work slot 0..5 */
     HvGLev l0 = (HvGLev)s0, l1 = (HvGLev)s1, l2 = (HvGLev)s2;
     HvGRec r0 = (HvGRec)(s0 + HV_TL * 1024 * 2), r1 = (HvGRec)(s1 + HV_TL * 1024 * 2), r2 = (HvGRec)(s2 + HV_TL * 1024 * 2);
@@ -2508,6 +2509,7 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
     const int ntrials = (n == 8) ? 71 : 70;
     const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
     HV_PROF_T0();
+    if (n == 8 && cl == 2) hv_cl_receive(S, im, cu);            /* cluster of 4: candidates 0..69 were evaluated elsewhere, the best of them joins candidate 70 */
     if (n > 8) {
         /* the split alternative is the state the children left behind  [ref :1409-1410]; it also bounds the pruning */
         if (hv_uni(wave) == 0) hv_job_sse(S, lane, cu);
@@ -2660,6 +2662,7 @@ static HD void hv_snapshot(HvLds &S, int lvl, int tid) {
 /* scope, every wait bounded (a partner that is not resident must not hang the GPU: the picture is then flagged and the host      */
 /* encodes it again without a cluster).  EXACT CTUs (re-analysis) are done by the chain workgroup alone, as without a cluster.     */
 /* --------------------------------------------------------------------------------------------- */
+#define HV_CL_BOX(lvl) (((lvl) + 2) % 3)                    /* mailbox of a CU level: 16x16 -> 0, 32x32 -> 1, 8x8 -> 2 */
 #define HV_CL_TIMEOUT 3000000000ull                          /* 30 s of the 100 MHz clock */
 static HD int hv_cl_wait(const int *seq, int want, int *fail) {   /* one thread */
     const unsigned long long t0 = hv_realtime();
@@ -2672,7 +2675,7 @@ static HD int hv_cl_wait(const int *seq, int want, int *fail) {   /* one thread 
 /* chain workgroup: the CU of level lvl is entered (S.ent / S.ent_ctx / S.lv[lvl] hold its entry state): tell the parent workgroup.
    All threads; what the parents read of the picture's reconstruction has been stored by now (fence below). */
 static HD void hv_cl_send(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, int kind) {
-    const int tid = hv_tid(), b = cu.lvl - 1;
+    const int tid = hv_tid(), b = HV_CL_BOX(cu.lvl);
     HevceMsg *m = &im.cluster->msg[b];
     const HvLds::Level &L = S.lv[cu.lvl];
     if (tid == 0) {
@@ -2688,14 +2691,14 @@ static HD void hv_cl_send(HvLds &S, const HevceImageDesc &im, const HvCu cu, int
 }
 /* chain workgroup, at the CU's decision: wait for the answer and make its candidate the only one alive of the level.  All threads. */
 static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu) {
-    const int tid = hv_tid(), b = cu.lvl - 1;
+    const int tid = hv_tid(), b = HV_CL_BOX(cu.lvl);
     HvLds::Level &L = S.lv[cu.lvl];
     const HevceRes *r = &im.cluster->res[b];
     if (tid == 0) { if (!hv_cl_wait(&r->seq, S.cl_seq[b], &S.cl_fail)) im.cluster->error = 1; }
     BLOCK_SYNC();
     const int w = hv_min(hv_max(r->winner, 0), 69);
-    if (tid < HV_TL) L.tdead[tid] = tid != w;
-    if (tid == 0) { L.tcost[w] = r->cost; L.tsse[w] = r->sse; L.tregs[w] = S.ent[cu.lvl]; L.tregs[w].range = r->range; L.tregs[w].nbits = r->nbits; L.tnlog[w] = 0; }
+    if (tid < HV_TL) L.tdead[tid] = tid != w && !(cu.lvl == 0 && tid == 70);   /* 8x8: the NxN candidate is the chain workgroup's own */
+    if (tid == 0) { L.tcost[w] = r->cost; L.tsse[w] = r->sse; L.tregs[w] = S.ent[cu.lvl]; L.tregs[w].range = r->range; L.tregs[w].nbits = r->nbits; L.tnlog[w] = 0; L.tpos[w] = -1; }
     if (tid < HEVCE_NCTXP) L.tctx[tid][w] = r->ctx[tid];
     BLOCK_SYNC();
 }
@@ -2716,9 +2719,13 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
     HvGLev glev = (HvGLev)scr;
     HvGRec grec = (HvGRec)(scr + HV_TL * 1024 * 2);
     if (stage == 0) {
-        if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = 0; L.tlen[tid] = 0; }
+        if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = tid < 70 ? 0 : -1; L.tlen[tid] = 0; }   /* candidate 70 (NxN) is not this workgroup's */
         if (tid == 0) L.best_cost = HV_I32MAX;
-        if (cu.n == 16) {
+        if (cu.n == 8) {
+            /* 3 chains (16 modes each) + 5 single blocks (8 modes each): one job per wavefront */
+            if (wv < 3) hv_job_chain<4>(wave, lane, q, cu, wv, glev, grec);
+            else hv_job_single<8>(wave, lane, q, cu, wv - 3, glev, grec);
+        } else if (cu.n == 16) {
             /* 5 chains (8 modes each) + 9 single blocks (4 modes each) over 8 wavefronts */
             if (wv < 5) hv_job_chain<8>(wave, lane, q, cu, wv, glev, grec);
             for (int j = (wv < 5 ? wv + 3 : wv - 5); j < 9; j += 8) hv_job_single<16>(wave, lane, q, cu, j, glev, grec);
@@ -2755,12 +2762,12 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
         }
         BLOCK_SYNC();
         const int w = hv_min(hv_max(S.winner, 0), 69);
-        HevceRes *r = &im.cluster->res[cu.lvl - 1];
+        HevceRes *r = &im.cluster->res[HV_CL_BOX(cu.lvl)];
         if (tid == 0) { r->cost = L.tcost[w]; r->winner = w; r->sse = L.tsse[w]; r->range = L.tregs[w].range; r->nbits = L.tregs[w].nbits - L.tnlog[w]; }
         if (tid < HEVCE_NCTXP) r->ctx[tid] = L.tctx[tid][w];
         hv_publish_fence();                                      /* the answer, and the winner's levels / samples in the level scratch */
         BLOCK_SYNC();
-        if (tid == 0) { const int sq = S.cl_seq[cu.lvl - 1] + 1; S.cl_seq[cu.lvl - 1] = sq; hv_st_release(&r->seq, sq); }
+        if (tid == 0) { const int sq = S.cl_seq[HV_CL_BOX(cu.lvl)] + 1; S.cl_seq[HV_CL_BOX(cu.lvl)] = sq; hv_st_release(&r->seq, sq); }
     }
     BLOCK_SYNC();
 }
@@ -2769,9 +2776,9 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
 static HD HvCu hv_pw_accept(HvLds &S, const HevceImageDesc &im, int b) {
     const int tid = hv_tid();
     const HevceMsg *m = &im.cluster->msg[b];
-    const int lvl = b + 1, ncx = im.W >> 5, ctu = m->ctu;
+    const int lvl = (b + 1) % 3, ncx = im.W >> 5, ctu = m->ctu;
     const int y0 = (ctu / ncx) * 32, x0 = (ctu % ncx) * 32;
-    HvCu cu = { m->y, m->x, m->n, m->n == 16 ? 4 : 5, lvl, m->L, m->LB, m->A, m->AR };
+    HvCu cu = { m->y, m->x, m->n, 3 + lvl, lvl, m->L, m->LB, m->A, m->AR };
     HvLds::Level &L = S.lv[lvl];
     if (tid == 0) {
         S.ent[lvl].range = m->range; S.ent[lvl].low = 0; S.ent[lvl].nbits = m->nbits; S.ent[lvl].nbytes = 0; S.ent[lvl].bufbyte = 0; S.ent[lvl].zeros = 0; S.ent[lvl].nout = 0; S.ent[lvl].pad = 0;
@@ -2793,13 +2800,13 @@ static HD HvCu hv_pw_accept(HvLds &S, const HevceImageDesc &im, int b) {
 /* The parent workgroup of a picture (cluster mode, second workgroup): it answers the chain workgroup's messages until told to
    exit.  16x16 CUs are answered at once (the chain needs them four rounds later); the 32x32 CU of a CTU, whose answer is due
    at the end of the CTU, is worked on stage by stage in between. */
-static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im) {
+static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve) {   /* serve: bit 0 = the 16x16 mailbox, bit 1 = the 32x32 mailbox */
     const int tid = hv_tid(), q = im.qpd6;
     if (tid == 0) { S.trace = nullptr; S.qlut = im.qlut; }
     BLOCK_SYNC();
     hv_init_tables(S, q, tid);
     hv_set_mode(S, 0, tid);
-    if (tid == 0) { S.cl_seq[0] = S.cl_seq[1] = 0; S.cl_fail = 0; S.cl_pick = 0; }
+    if (tid == 0) { S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_fail = 0; S.cl_pick = 0; }
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
     BLOCK_SYNC();
@@ -2811,9 +2818,10 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im) {
             const unsigned long long t0 = hv_realtime();
             int pick = 0;
             for (;;) {
-                if (hv_ld_acquire(&C->msg[0].seq) == S.cl_seq[0] + 1) { pick = 1; break; }              /* a 16x16 CU (or the exit message): first */
+                if ((serve & 4) && hv_ld_acquire(&C->msg[2].seq) == S.cl_seq[2] + 1) { pick = 4; break; }   /* an 8x8 CU (or the exit message) */
+                if ((serve & 1) && hv_ld_acquire(&C->msg[0].seq) == S.cl_seq[0] + 1) { pick = 1; break; }   /* a 16x16 CU (or the exit message): first */
                 if (stage32 >= 0) { pick = 2; break; }                                                   /* the 32x32 CU in progress */
-                if (hv_ld_acquire(&C->msg[1].seq) == S.cl_seq[1] + 1) { pick = 3; break; }              /* a new 32x32 CU */
+                if ((serve & 2) && hv_ld_acquire(&C->msg[1].seq) == S.cl_seq[1] + 1) { pick = 3; break; }   /* a new 32x32 CU (or the exit message) */
                 if (hv_realtime() - t0 > HV_CL_TIMEOUT) { pick = -1; C->error = 2; break; }
                 hv_spin_pause();
             }
@@ -2823,12 +2831,16 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im) {
         const int pick = hv_uni(S.cl_pick);
         BLOCK_SYNC();
         if (pick < 0) break;
-        if (pick == 1) {
-            if (C->msg[0].kind == 2) break;
-            const HvCu cu = hv_pw_accept(S, im, 0);
+        if (pick == 1 || pick == 4) {
+            const int b = pick == 1 ? 0 : 2;
+            if (C->msg[b].kind == 2) break;
+            const HvCu cu = hv_pw_accept(S, im, b);
             for (int st = 0; st < 3; st++) hv_pw_stage(S, im, cu, st);
         } else {
-            if (pick == 3) { c32 = hv_pw_accept(S, im, 1); stage32 = 0; }   /* a 16x16 CU served in between reloads the same CTU's samples: harmless */
+            if (pick == 3) {
+                if (C->msg[1].kind == 2) break;
+                c32 = hv_pw_accept(S, im, 1); stage32 = 0;               /* a 16x16 CU served in between reloads the same CTU's samples: harmless */
+            }
             hv_pw_stage(S, im, c32, stage32);
             stage32 = stage32 == 2 ? -1 : stage32 + 1;
         }
@@ -2883,7 +2895,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int force_exact = (im.flags & 1) || !im.payload;      /* without the writer nothing vouches for the FAST decisions */
     const int pk_nxn = (im.flags >> 8) & 0xff, pk_wr = (im.flags >> 16) & 0xff;
     hv_set_mode(S, force_exact, tid);
-    if (tid == 0) { S.poison = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = 0; S.cl_fail = 0; }
+    if (tid == 0) { S.poison = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_fail = 0; }
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
     BLOCK_SYNC();
@@ -2893,6 +2905,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
         const int exact = hv_uni(S.exact);
         const int tail = ctu == nctu;                            /* past the last CTU: only the writer has work left */
         const int cl = im.cluster != nullptr && !exact;          /* the parent workgroup evaluates this CTU's 16x16 / 32x32 CUs */
+        const int cl8 = cl && im.cluster->size >= 4;             /* ... and a fourth workgroup the 8x8 CUs' candidates 0..69 */
         const int wr_on = im.payload && ctu > 0 && hv_uni(S.wr_done) < ctu;   /* the writer does CTU ctu - 1 during this round */
         const int y0 = (ctu / ncx) * 32, x0 = (ctu % ncx) * 32;
         if (wr_on && tid == 4 * 64) { S.wsnap = S.wr; S.wr_epb = 0; }
@@ -2962,11 +2975,17 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     hv_snapshot(S, 0, tid);
                     hv_level_begin(S, cu);
                     BLOCK_SYNC();
+                    if (cl8) {
+                        /* the candidates of this CU other than the NxN one are another workgroup's: only candidate 70 runs here */
+                        if (tid < 70) { S.lv[0].tdead[tid] = 1; S.lv[0].tpos[tid] = -1; }
+                        if (tid == 0) S.l0_active = 1;
+                        hv_cl_send(S, im, cu, ctu, 1);
+                    }
                     HV_PROF_T0();
 #ifdef HEVCE_PROF_JDUR
                     const unsigned long long j0_ = __builtin_amdgcn_s_memtime();
 #endif
-                    hv_jobs_phase(S, im, cu, c16, c32, k, m, ctu, wr_on, cl);
+                    hv_jobs_phase(S, im, cu, c16, c32, k, m, ctu, wr_on, cl + cl8);
 #ifdef HEVCE_PROF_JDUR
                     if (tid == HEVCE_PROF_JDUR * 64) S.prof2[16 + k * 4 + m] += __builtin_amdgcn_s_memtime() - j0_;   /* that wavefront's jobs phase, riders included */
 #endif
@@ -2984,8 +3003,8 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     }
                     hv_engine_phase(S, im, cl ? 1 : (1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0)), 0);
                 }
-                hv_decide_cu(S, im, cu, ctu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr, cl);
-                if (cl && cu.n == 16) hv_cl_store_rcon(S, im, cu, y0, x0);   /* the next 16x16 CU's parents predict from these samples */
+                hv_decide_cu(S, im, cu, ctu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr, cl + cl8);
+                if (cl && (cu.n == 16 || (cl8 && cu.n == 8))) hv_cl_store_rcon(S, im, cu, y0, x0);   /* the next CU's candidates elsewhere predict from these samples */
             }
 
         }
@@ -3048,9 +3067,11 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
         ctu++;
     }
     if (im.cluster) {                                            /* the parent workgroup may go home */
-        const HvCu none = { 0, 0, 16, 4, 1, 0, 0, 0, 0 };
+        const HvCu none16 = { 0, 0, 16, 4, 1, 0, 0, 0, 0 }, none32 = { 0, 0, 32, 5, 2, 0, 0, 0, 0 };
         BLOCK_SYNC();
-        hv_cl_send(S, im, none, nctu, 2);
+        hv_cl_send(S, im, none16, nctu, 2);                      /* on both mailboxes: one workgroup may serve both, or one each */
+        hv_cl_send(S, im, none32, nctu, 2);
+        if (im.cluster->size >= 4) { const HvCu none8 = { 0, 0, 8, 3, 0, 0, 0, 0, 0 }; hv_cl_send(S, im, none8, nctu, 2); }
     }
     if (im.stats && tid == 0) { im.stats[0] = n_redo; im.stats[1] = n_bad + S.cl_fail; }
     if (S.cl_fail && im.payload_len && tid == 0) *im.payload_len = -1;   /* a hand-off timed out: the host encodes the picture again without a cluster */

@@ -129,7 +129,7 @@ struct hevce_job {
     uint8_t *h_streams = nullptr; size_t h_streams_bytes = 0;   /* pinned: header + slice data of every picture, back to back; grows on demand */
     bool device_emit = true;         /* the kernel emits the slice data itself; HEVCE_HOST_WRITER=1: replay the records on the host instead */
     int flags = 0;                   /* HevceImageDesc.flags (tests: HEVCE_FLAGS) */
-    bool cluster = false;            /* two workgroups per picture (hevce_device.h): when both fit the device side by side */
+    int cluster = 1;                 /* workgroups per picture (hevce_device.h cluster mode): as many (<= 3) as fit the device side by side */
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     float kernel_ms = 0, d2h_ms = 0, writer_ms = 0;
@@ -191,8 +191,8 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
         hipDeviceProp_t prop;
         int cus = 0;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
-        j->cluster = j->device_emit && cus >= 2 && 2 * n <= cus;
-        if (const char *e = getenv("HEVCE_CLUSTER")) j->cluster = j->cluster && atoi(e) != 0;
+        j->cluster = !j->device_emit ? 1 : (4 * n <= cus ? 4 : (3 * n <= cus ? 3 : (2 * n <= cus ? 2 : 1)));
+        if (const char *e = getenv("HEVCE_CLUSTER")) { const int mx = atoi(e); if (mx >= 0 && mx < j->cluster) j->cluster = mx < 1 ? 1 : mx; }
     }
     if (getenv("HEVCE_DUMP")) {
         for (int i = 0; i < n; i++) j->dump_ints += size_t(j->im[i].nctu) * 21 * HEVCE_TRIALS * 16;
@@ -303,17 +303,22 @@ int hevce_job_launch(hevce_job *j) {
             d.payload = j->device_emit ? j->d_slab + m.off_payload : nullptr;
             d.stats = (int32_t *)(j->d_slab + m.off_stats);
             d.wr_tok = j->d_slab + m.off_wrtok;
-            d.cluster = (j->cluster && !(j->flags & 2)) ? (HevceCluster *)(j->d_slab + m.off_cluster) : nullptr;
+            d.cluster = (j->cluster > 1 && !(j->flags & 2)) ? (HevceCluster *)(j->d_slab + m.off_cluster) : nullptr;
             d.flags = j->flags; d.pad_ = 0;
             d.payload_len = j->device_emit ? (int32_t *)(j->d_slab + m.off_plen) : nullptr;
         }
         HIPCHK(hipMemcpyAsync(j->d_desc, j->h_desc.data(), sizeof(HevceImageDesc) * j->n, hipMemcpyHostToDevice, j->stream));
         j->desc_dirty = false;
     }
-    const bool cluster = j->cluster && !(j->flags & 2);
-    if (cluster) for (int i = 0; i < j->n; i++) HIPCHK(hipMemsetAsync(j->d_slab + j->im[i].off_cluster, 0, sizeof(HevceCluster), j->stream));   /* sequence words start at 0 */
+    const int cluster = (j->cluster > 1 && !(j->flags & 2)) ? j->cluster : 1;
+    if (cluster > 1) {
+        HevceCluster init;
+        memset(&init, 0, sizeof init);                           /* sequence words start at 0 */
+        init.size = cluster;
+        for (int i = 0; i < j->n; i++) HIPCHK(hipMemcpyAsync(j->d_slab + j->im[i].off_cluster, &init, sizeof init, hipMemcpyHostToDevice, j->stream));
+    }
     HIPCHK(hipEventRecord(j->ev0, j->stream));
-    if (hevce_launch_analyse(j->d_desc, j->n, cluster ? 1 : 0, j->stream) != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (hevce_launch_analyse(j->d_desc, j->n, cluster, j->stream) != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     HIPCHK(hipEventRecord(j->ev1, j->stream));
     /* what the host needs in every case: the length of each picture's slice data.  The decision records and per-CTU coder
        registers (2176 + 32 bytes per CTU) only travel when somebody wants them: the host-writer mode, hevce_job_download_records */
@@ -347,11 +352,11 @@ int hevce_job_finish(hevce_job *j) {
         for (int i = 0; i < j->n; i++) {
             Image &m = j->im[i];
             const int plen = *(const int32_t *)(j->h_slab + m.hoff_plen);
-            if (plen == -1 && j->cluster && !(j->flags & 2)) {
+            if (plen == -1 && j->cluster > 1 && !(j->flags & 2)) {
                 /* a hand-off between a picture's two workgroups timed out (they were not resident side by side): once more, one
                    workgroup per picture */
                 fprintf(stderr, "hevce_mi355x: cluster hand-off timed out (image %d); encoding again without clusters\n", i);
-                j->cluster = false; j->desc_dirty = true;
+                j->cluster = 1; j->desc_dirty = true;
                 if (hevce_job_launch(j) != 0) return -1;
                 return hevce_job_finish(j);
             }

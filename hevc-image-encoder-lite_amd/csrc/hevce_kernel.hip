@@ -5,17 +5,18 @@
 
 extern "C" __global__ void __launch_bounds__(HV_NTHREADS, 2)
 hevce_analyse_kernel(const HevceImageDesc *__restrict__ images, int nimages, int cluster) {
-    /* cluster mode: two workgroups per picture -- 2 i walks picture i's chain of decisions, 2 i + 1 evaluates its 16x16 / 32x32 CUs */
-    const int b = blockIdx.x, pic = cluster ? b >> 1 : b;
+    /* cluster mode: `cluster` (2, 3 or 4) workgroups per picture -- the first walks the picture's chain of decisions, the others
+       evaluate candidates for it: the 16x16 / 32x32 CUs (one workgroup for both levels, or one each), with four also the 8x8 CUs' */
+    const int b = blockIdx.x, pic = cluster > 1 ? b / cluster : b, role = cluster > 1 ? b % cluster : 0;
     if (pic >= nimages) return;
     const HevceImageDesc im = images[pic];
-    if (cluster && (b & 1)) hv_parent_worker(HV_S, im);
-    else hv_analyse_image(HV_S, im);
+    if (role == 0) hv_analyse_image(HV_S, im);
+    else hv_parent_worker(HV_S, im, cluster == 2 ? 3 : (role == 3 ? 4 : role));
 }
 
-/* host-side launcher used by hevce_host.cpp: grid = images of the batch (twice that in cluster mode) */
+/* host-side launcher used by hevce_host.cpp: grid = images of the batch (times the cluster size) */
 extern "C" int hevce_launch_analyse(const HevceImageDesc *d_images, int n, int cluster, hipStream_t stream) {
-    hipLaunchKernelGGL(hevce_analyse_kernel, dim3((unsigned)(cluster ? 2 * n : n)), dim3(HV_NTHREADS), 0, stream, d_images, n, cluster);
+    hipLaunchKernelGGL(hevce_analyse_kernel, dim3((unsigned)(cluster > 1 ? cluster * n : n)), dim3(HV_NTHREADS), 0, stream, d_images, n, cluster);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

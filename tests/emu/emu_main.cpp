@@ -6,16 +6,17 @@
 
 int emu_cur = 0;
 HvLds *emu_lds_ptr = nullptr;
-int emu_stage[16][64];
+int emu_stage[32][64];
 
 namespace {
-enum { NT = HV_NTHREADS, NWG = 2, STACK = 256 * 1024 };
+enum { NT = HV_NTHREADS, NWG = 4, STACK = 256 * 1024 };
 enum State { RUN, WAIT_WAVE, WAIT_BLOCK, DONE };
 struct Fiber { void *sp; State st; char *stack; };
 Fiber fib[NWG * NT];
 void *sched_sp;
 int wave_wait[NWG * 8], block_wait[NWG], ndone;
 HvLds *g_lds[NWG];
+int g_nwg = 1;
 const HevceImageDesc *g_im;
 
 extern "C" void emu_switch(void **save_sp, void *new_sp);
@@ -43,7 +44,8 @@ emu_switch:
 void yield_to_sched() { emu_switch(&fib[emu_cur].sp, sched_sp); }
 
 void fiber_entry() {
-    if (emu_cur >= NT) hv_parent_worker(*g_lds[1], *g_im);       /* cluster mode: the second workgroup */
+    const int role = emu_cur / NT;                               /* cluster mode: workgroup 0 = chain, the others = parents */
+    if (role) hv_parent_worker(*g_lds[role], *g_im, g_nwg == 2 ? 3 : (role == 3 ? 4 : role));
     else hv_analyse_image(*g_lds[0], *g_im);
     fib[emu_cur].st = DONE;
     ndone++;
@@ -86,10 +88,12 @@ int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, 
     im.W = ((src_w < HEVCE_MAXDIM ? src_w : HEVCE_MAXDIM) + 31) / 32 * 32;
     std::vector<uint8_t> scratch(HEVCE_SCRATCH_BYTES, 0xCD);
     im.scratch = scratch.data();
-    const int nwg = cluster ? 2 : 1, nfib = nwg * NT;
+    const int nwg = cluster > 1 ? cluster : 1, nfib = nwg * NT;
+    g_nwg = nwg;
     static HevceCluster cl;
     memset(&cl, 0, sizeof cl);
-    im.cluster = cluster ? &cl : nullptr;
+    cl.size = cluster;
+    im.cluster = cluster > 1 ? &cl : nullptr;
     for (int g = 0; g < nwg; g++) {
         g_lds[g] = (HvLds *)aligned_alloc(64, (sizeof(HvLds) + 63) / 64 * 64);
         memset(g_lds[g], 0xAB, sizeof(HvLds));                /* LDS is not zero-initialised on the GPU either */
@@ -126,7 +130,7 @@ int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, 
                 progress = true;
             }
         if (!progress) {
-            fprintf(stderr, "emu: deadlock (divergent synchronisation): block_wait=%d %d done=%d waves:", block_wait[0], block_wait[1], ndone);
+            fprintf(stderr, "emu: deadlock (divergent synchronisation): block_wait=%d %d %d %d done=%d waves:", block_wait[0], block_wait[1], block_wait[2], block_wait[3], ndone);
             for (int w = 0; w < nwg * 8; w++) fprintf(stderr, " %d", wave_wait[w]);
             fprintf(stderr, "\n");
             rc = -1;
@@ -135,7 +139,7 @@ int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, 
     }
     for (int i = 0; i < nfib; i++) free(fib[i].stack);
     for (int g = 0; g < nwg; g++) free(g_lds[g]);
-    if (cluster && cl.error) rc = -2;
+    if (cluster > 1 && cl.error) rc = -2;
     return rc;
 }
 extern "C" __attribute__((visibility("default"))) int emu_lds_bytes(void) { return (int)sizeof(HvLds); }

@@ -59,14 +59,15 @@ def test_emulated_kernel_reanalysis_paths(path, flags):
     assert (redo > 0) == (flags != 1)
 
 
+@pytest.mark.parametrize("nwg", [2, 3, 4])
 @pytest.mark.parametrize("flags", [0, 2 << 8, 3 << 16], ids=["fast", "nxn2", "wr3"])
 @pytest.mark.parametrize("path", MODE_CASES, ids=lambda p: os.path.basename(p)[6:-4])
-def test_emulated_cluster_of_two_workgroups(path, flags):
-    """cluster mode (hevce_device.h hv_parent_worker): the chain workgroup and the parent workgroup of one picture as 2 x 512
+def test_emulated_cluster_of_workgroups(path, flags, nwg):
+    """cluster mode (hevce_device.h hv_parent_worker): the chain workgroup and the parent workgroup(s) of one picture as 2 / 3 x 512
     fibers exchanging messages through the HevceCluster mailboxes; also with re-analysed CTUs, which the chain workgroup does alone."""
     import emu
     c = load_case(path)
-    rec, rcon, st = emu.analyse(c["img"], c["q"], flags=flags, cluster=1)
+    rec, rcon, st = emu.analyse(c["img"], c["q"], flags=flags, cluster=nwg)
     assert np.array_equal(rcon, c["rcon"]) and np.array_equal(st, c["ctu_state"]) and np.array_equal(rec, c["records"])
     assert bytes(c["stream"]).endswith(emu.analyse.payload) and len(emu.analyse.payload) > 0
     assert emu.analyse.stats[1] == 0
