@@ -76,6 +76,7 @@ static HD int  hv_peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELA
 static HD int  hv_poll(const int *p) { return hv_peek(p); }      /* value other wavefronts are changing meanwhile */
 static HD void hv_atomic_dec(int *p) { atomicSub(p, 1); }
 static HD void hv_flag_clear(int *p) { __hip_atomic_store(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+static HD void hv_flag_set(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define HV_FENCE_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
 static HD int  hv_mul24(int a, int b) { return __mul24(a, b); }
 static HD unsigned hv_umul24(unsigned a, unsigned b) { return __umul24(a, b); }   /* both < 2^24: low 32 bits of the product, full rate */
@@ -255,6 +256,7 @@ struct alignas(16) HvLds {
     };
     int   nxn_ntok[35];                                     /* per mode of the current 4x4 block: tokens | bypass bins << 8 | bits << 20 */
     int   c70_len, c70_byp;                                 /* tokens / bypass bins of candidate 70's stream so far */
+    int   c70_done, c70_seg[4], c70_pat;                    /* FAST: stages whose winner's tokens are in the stream (5: header known too); per stage offset | tokens << 16 | cbf << 31; the CU header's four prev_intra_luma_pred_flags */
     u8    nxn_ctx[HEVCE_NCTXP][HV_TL];                      /* context columns of the NxN chain's 35 modes (fresh per 4x4 block) */
     /* control */
     int cl_seq[3];                                          /* cluster mode: messages sent (chain workgroup) / answered (parent workgroup) per mailbox */
@@ -1751,6 +1753,11 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
             }
             WAVE_SYNC();
             if (lane == 0) { S.c70_len = off + 1 + n; S.c70_byp += cbf ? ((pk >> 8) & 0xfff) : 0; }
+            if constexpr (FAST) {
+                /* candidate 70's rider (hv_c70_rider, another wavefront) may code this block now */
+                HV_FENCE_RELEASE();
+                if (lane == 0) { S.c70_seg[s] = off | (n << 16) | (cbf << 31); hv_flag_set(&S.c70_done, s + 1); }
+            }
         }
         WAVE_SYNC();
         HV_PROF2(S, 3);
@@ -1774,8 +1781,14 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
         S.slist0[70][0] = (u16)(((len + 7) >> 3) << 8);          /* slot 0, that many chunks */
         L.tlen[70] = 1; L.tpos[70] = 0; L.tnlog[70] = FAST ? S.c70_byp + wh.byp : 0;   /* FAST: tnlog = the candidate's bypass bins */
         L.tregs[70] = S.ent[0];
+        if constexpr (FAST) {                                    /* which of the four luma modes are most-probable-mode hits: the rider's lane  [ref :985-1018] */
+            int pat = 0;
+            for (int i = 0; i < 4; i++) { int p3[3]; hv_mpm(pm.left[i], pm.above[i], p3); pat |= (p3[0] == pm.mode[i] || p3[1] == pm.mode[i] || p3[2] == pm.mode[i]) << i; }
+            S.c70_pat = pat;
+        }
     }
     for (int r = lane; r < HEVCE_NCTXP; r += 64) L.tctx[r][70] = S.ent_ctx[0][r];
+    if constexpr (FAST) { HV_FENCE_RELEASE(); WAVE_SYNC(); if (lane == 0) hv_flag_set(&S.c70_done, 5); }
     HV_PROF2(S, 4);
 }
 /* distortion of the CU as currently reconstructed (the "split into four CUs" alternative)  [ref :1409] */
@@ -1874,7 +1887,7 @@ static HD void hv_level_begin(HvLds &S, const HvCu cu) {
     }
     if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = 0; L.tlen[tid] = 0; }
     if (n == 8) for (int k = tid; k < 8 * 8; k += HV_NTHREADS) (&S.nxn_crec[0][0])[k] = 0;
-    if (n == 8 && tid == 0) { S.nxn_busy = 1; S.l0_active = 71; }
+    if (n == 8 && tid == 0) { S.nxn_busy = 1; S.l0_active = 71; S.c70_done = 0; }
 }
 
 /* chunks per slot of the candidates a wavefront is binarising: rows of HEVCE_TOKEN_SLOTS + 2 bytes, row 0 = candidate t0, in
@@ -2426,6 +2439,7 @@ static HDN void hv_wr_engine(const HevceImageDesc &im_, int cw, int budget) {
      3. in the time the NxN chain still takes, the prepared candidates of the enclosing CUs ride on.
    The schedule is static and wave-uniform (SGPRs): no lane-dependent control flow may surround the jobs (wave shuffles). */
 #define HV_JOBT(slot, call) call
+static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q);
 static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m, int ctu, int wr_on, int cl) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
     const int wv = hv_uni(wave);
@@ -2449,7 +2463,10 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         }
         return;
     }
-    if (hv_uni(cl) == 2) return;                                 /* cluster of 4: this CU's block jobs and candidates 0..69 are another workgroup's */
+    if (hv_uni(cl) == 2) {                                       /* cluster of 4: this CU's block jobs and candidates 0..69 are another workgroup's */
+        if (wv == 5) hv_c70_rider((HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3) + (size_t)70 * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0, q);
+        return;
+    }
     const int w1 = wv < 4 ? wv - 1 : wv - 2;                     /* work slot 0..5 */
     HvGLev l0 = (HvGLev)s0, l1 = (HvGLev)s1, l2 = (HvGLev)s2;
     HvGRec r0 = (HvGRec)(s0 + HV_TL * 1024 * 2), r1 = (HvGRec)(s1 + HV_TL * 1024 * 2), r2 = (HvGRec)(s2 + HV_TL * 1024 * 2);
@@ -2650,6 +2667,55 @@ static HD void hv_init_sigtab(HvLds &S, int tid) {
 static HD void hv_snapshot(HvLds &S, int lvl, int tid) {
     if (tid == 0) S.ent[lvl] = S.com;
     if (tid < HEVCE_NCTXP) S.ent_ctx[lvl][tid] = S.com_ctx[tid];
+}
+
+/* Candidate 70's rider (cluster of four: the chain workgroup's other wavefronts are free).  Candidate 70 -- the CU coded as four
+   4x4 blocks with the NxN chain's winning modes -- can only be costed from the CU's entry state when the chain is done: its
+   CU header comes first and holds the four prev_intra_luma_pred_flags, which depend on all four modes  [ref :985-1018,
+   1531-1541].  But the header's other bins are the same whatever the modes, the flags are four bins on one context, and bypass
+   bins do not move the range: so SIXTEEN lanes code the candidate at once, one per flag pattern, block by block as the chain
+   delivers the winners' tokens (the tokens are the same in every lane), and when the chain has fixed the modes the lane of the
+   pattern that came true IS candidate 70.  Only the last block's tokens are left to code when the chain ends. */
+static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q) {
+    HvLds &S = HV_S;
+    HvLds::Level &L = S.lv[0];
+    const int lane = hv_tid() & 63, pl = lane & 15, act = lane < 16;
+    q = hv_uni(q);
+    HV_LDSP u16 *stage = (HV_LDSP u16 *)&S.ws[hv_tid() >> 6];     /* the block's tokens, fetched by the whole wavefront */
+    u8 *cx = &L.tctx[0][pl];                                     /* context columns 0..15 of the level: its candidates 0..69 live elsewhere */
+    for (int r = lane >> 4; r < HEVCE_NCTXP; r += 4) L.tctx[r][pl] = S.ent_ctx[0][r];
+    WAVE_SYNC();
+    HvFCod c = { S.ent[0].range, S.ent[0].nbits };
+    if (act) {                                                                                              /* [ref :952-955, 985-1033] */
+        hv_fbin(S, c, HV_CX(CX_PART), 0);
+        for (int i = 0; i < 4; i++) hv_fbin(S, c, HV_CX(CX_YPM), (pl >> i) & 1);
+        hv_fbin(S, c, HV_CX(CX_UVPM), 0);
+        hv_fbin(S, c, HV_CX(CX_UVCBF), 0);
+        hv_fbin(S, c, HV_CX(CX_UVCBF), 0);
+    }
+    for (int s = 0; s < 4; s++) {
+        while (hv_poll(&S.c70_done) <= s) hv_spin_pause();
+        const int seg = hv_uni(S.c70_seg[s]), off = seg & 0xffff, n = (seg >> 16) & 0x7fff, cbf = (seg >> 31) & 1;
+        for (int t = lane; t < n; t += 64) stage[t] = (u16)(hv_ldg_u32((const unsigned *)(c70 + ((off + 1 + t) & ~1))) >> (((off + 1 + t) & 1) << 4));
+        WAVE_SYNC();
+        if (act) {
+            hv_fbin(S, c, HV_CX(CX_YCBF), cbf);                                                             /* [ref :1038-1043] */
+            HV_NOUNROLL for (int t = 0; t < n; t++) {
+                const int tok = stage[t];
+                hv_fbin(S, c, cx + (tok & 0x1fff), (tok >> 14) & 1);
+            }
+        }
+        WAVE_SYNC();
+    }
+    while (hv_poll(&S.c70_done) < 5) hv_spin_pause();
+    const int pat = hv_uni(S.c70_pat) & 15;
+    if (lane == pat) {
+        const int byp = L.tnlog[70];
+        L.tregs[70].range = c.range; L.tregs[70].nbits = c.nbits;
+        L.tcost[70] = hv_rdcost(q, L.tsse[70], S.ent[0].nbits - c.nbits + byp);
+        L.tdead[70] = 0; L.tpos[70] = -1;
+    }
+    for (int r = lane; r < HEVCE_NCTXP; r += 64) L.tctx[r][70] = L.tctx[r][pat];
 }
 
 /* --------------------------------------------------------------------------------------------- */
@@ -3001,7 +3067,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                         if (m == 0) hv_level_contexts(S, im, c16);
                         if (k == 1 && m == 2) hv_level_contexts(S, im, c32);     /* its jobs ran in five phases up to this one */
                     }
-                    hv_engine_phase(S, im, cl ? 1 : (1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0)), 0);
+                    if (!cl8) hv_engine_phase(S, im, cl ? 1 : (1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0)), 0);   /* cluster of 4: candidate 70 has been coded by its rider */
                 }
                 hv_decide_cu(S, im, cu, ctu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr, cl + cl8);
                 if (cl && (cu.n == 16 || (cl8 && cu.n == 8))) hv_cl_store_rcon(S, im, cu, y0, x0);   /* the next CU's candidates elsewhere predict from these samples */

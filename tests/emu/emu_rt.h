@@ -57,6 +57,7 @@ void emu_yield(void);
 static inline int hv_poll(const int *p) { emu_yield(); return *p; }   /* lets the fibers that change *p run */
 static inline void hv_atomic_dec(int *p) { (*p)--; }
 static inline void hv_flag_clear(int *p) { *p = 0; }
+static inline void hv_flag_set(int *p, int v) { *p = v; }
 #define HV_FENCE_RELEASE() do { } while (0)
 static inline int hv_mul24(int a, int b) {
     if (a < -(1 << 23) || a >= (1 << 23) || b < -(1 << 23) || b >= (1 << 23)) { fprintf(stderr, "emu: mul24 operand out of range %d %d\n", a, b); abort(); }
