@@ -256,6 +256,7 @@ struct alignas(16) HvLds {
     };
     int   nxn_ntok[35];                                     /* per mode of the current 4x4 block: tokens | bypass bins << 8 | bits << 20 */
     int   c70_len, c70_byp;                                 /* tokens / bypass bins of candidate 70's stream so far */
+    int   nxq_go, nxq_done;                                 /* cluster of four: 4x4 blocks whose reference samples are laid out; helper wavefronts done, in all */
     int   c70_done, c70_seg[4], c70_pat;                    /* FAST: stages whose winner's tokens are in the stream (5: header known too); per stage offset | tokens << 16 | cbf << 31; the CU header's four prev_intra_luma_pred_flags */
     u8    nxn_ctx[HEVCE_NCTXP][HV_TL];                      /* context columns of the NxN chain's 35 modes (fresh per 4x4 block) */
     /* control */
@@ -1639,9 +1640,143 @@ static HD int hv_tu4_lane(const HvLds &S, int q, const u8 *b, u8 *line_buf, int 
     return sse;
 }
 
+/* The same 4x4 block trial with FOUR lanes per mode (lane = mode * 4 + row): a helper wavefront of the chain workgroup does 16
+   modes at a quarter of the instructions per lane; three of them stand in for hv_tu4_lane when the workgroup's other wavefronts
+   are free (cluster of four).  Rows and columns change hands through a 32-byte tile per mode in the wavefront's scratch.
+   Results go where hv_tu4_lane puts them: S.nxn_lev / nxn_rec / nxn_sse / nxn_last / nxn_sig of the mode.  [ref :1508-1518] */
+static HD void hv_tu4_quad(HvLds &S, int q, int ty, int tx, int m, int ok) {
+    const int lane = hv_tid() & 63, qd = lane >> 2, i = lane & 3;
+    HvWaveScr &W = S.ws[hv_tid() >> 6];
+    HV_LDSP short *tile = (HV_LDSP short *)W.scr + qd * 16;       /* [4][4] 16-bit, exchanged between the mode's four lanes */
+    HV_LDSP u8 *line = (HV_LDSP u8 *)W.pred + qd * 16 + 4;        /* the mode's reference line r(-4..9) */
+    const u8 *b = S.nxn_bord, *l = b + 1, *a = b + 9;
+    const int c = b[0];
+    m = ok ? m : 1;
+    const bool horiz = m < 18;
+    const int ang = S.ang[m], inv = S.invang[m];
+    {   /* reference line: lane i lays out r(4 i - 4 .. 4 i - 1)  [ref :353-364] */
+        const u8 *mainr = horiz ? l : a, *sider = horiz ? a : l;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int k = 4 * i - 4 + e;
+            const int vm = mainr[hv_min(hv_max(k, 1), 8) - 1], vs = sider[hv_min(hv_max(((128 - inv * k) >> 8) - 1, 0), 7)];
+            line[k] = (u8)(k > 0 ? vm : (k == 0 ? c : vs));
+        }
+    }
+    WAVE_SYNC();
+    /* prediction of row i: all forms, the mode's own selected  [ref :262-381] */
+    int p[4];
+    {
+        const int Li = l[i], L4 = l[4], A4 = a[4], L0 = l[0], A0 = a[0];
+        int dc = 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) dc += l[k] + a[k];
+        dc >>= 3;
+        const bool planar = m == 0, isdc = m == 1, hor = m == 10, ver = m == 26;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const int Ax = a[x];
+            const int st = horiz ? x : i, al = horiz ? i : x;
+            const int off = ang * (st + 1), oi = off >> 5, of = off & 31, k1 = oi + al + 1;
+            int v = (hv_mul24(32 - of, line[k1]) + hv_mul24(of, line[k1 + 1]) + 16) >> 5;
+            const int pl = (4 + (3 - x) * Li + (x + 1) * A4 + (3 - i) * Ax + (i + 1) * L4) >> 3;
+            const int dv = (i == 0 && x == 0) ? (2 + 2 * dc + L0 + A0) >> 2 : (i == 0) ? (2 + 3 * dc + Ax) >> 2 : (x == 0) ? (2 + 3 * dc + Li) >> 2 : dc;
+            v = (i == 0 && hor) ? hv_clip8(L0 + ((Ax - c) >> 1)) : v;      /* edge filters of the pure directions */
+            v = (x == 0 && ver) ? hv_clip8(A0 + ((Li - c) >> 1)) : v;
+            p[x] = planar ? pl : (isdc ? dv : v);
+        }
+    }
+    constexpr int D[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };       /* [ref :391-396] */
+    /* residual row i -> tile, read back as column i */
+    int r[4], t[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) tile[x * 4 + i] = (short)((int)S.org[ty + i][tx + x] - p[x]);      /* stored transposed: tile[column][row] */
+    WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = tile[i * 4 + k];                                            /* r[k] = residual(row k, column i) */
+    WAVE_SYNC();
+    /* forward, columns (shift 1): t[k] = coefficient (k, column i) */
+#pragma unroll
+    for (int k = 0; k < 4; k++) t[k] = (hv_mul24(D[k * 4], r[0]) + hv_mul24(D[k * 4 + 1], r[1]) + hv_mul24(D[k * 4 + 2], r[2]) + hv_mul24(D[k * 4 + 3], r[3]) + 1) >> 1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) tile[k * 4 + i] = (short)t[k];                                      /* tile[row][column] */
+    WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < 4; k++) t[k] = tile[i * 4 + k];                                            /* row i of the intermediate */
+    WAVE_SYNC();
+    /* forward, rows (shift 8), quantiser  [ref :540-595] */
+    const int sh = 19 + q, thr = 9 << sh >> 2, qsh = 5 + q;
+    const HvQlut lut = hv_qlut<2>(S);
+    int cf[4], lv[4], sum = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        cf[x] = (hv_mul24(t[0], D[x * 4]) + hv_mul24(t[1], D[x * 4 + 1]) + hv_mul24(t[2], D[x * 4 + 2]) + hv_mul24(t[3], D[x * 4 + 3]) + 128) >> 8;
+        int d;
+        lv[x] = hv_quant_lut(lut, hv_abs(cf[x]), d);
+        sum += hv_min(d, thr);
+    }
+    sum += hv_shfl_xor(sum, 1);
+    sum += hv_shfl_xor(sum, 2);
+    const int zero = sum < thr;
+    const int kind = hv_scan_kind(4, m);
+    int last = -1;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        lv[x] = zero ? 0 : (cf[x] < 0 ? -lv[x] : lv[x]);
+        const int si = kind == 0 ? S.d4idx[(i << 2) | x] : (kind == 1 ? i * 4 + x : x * 4 + i);
+        if (ok) S.nxn_lev[m][si] = (short)lv[x];
+        last = (lv[x] != 0 && si > last) ? si : last;
+        tile[i * 4 + x] = (short)hv_clip16((int)((unsigned)lv[x] << qsh));                            /* dequantised, tile[row][column] */
+    }
+    last = hv_max(last, hv_shfl_xor(last, 1));
+    last = hv_max(last, hv_shfl_xor(last, 2));
+    WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = tile[k * 4 + i];                                            /* column i */
+    WAVE_SYNC();
+    /* inverse: columns with C^T (shift 7), rows (shift 12) */
+#pragma unroll
+    for (int k = 0; k < 4; k++) t[k] = hv_clip16((hv_mul24(D[k], r[0]) + hv_mul24(D[4 + k], r[1]) + hv_mul24(D[8 + k], r[2]) + hv_mul24(D[12 + k], r[3]) + 64) >> 7);
+#pragma unroll
+    for (int k = 0; k < 4; k++) tile[k * 4 + i] = (short)t[k];
+    WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < 4; k++) t[k] = tile[i * 4 + k];                                            /* row i */
+    int sse = 0;
+    unsigned rc4 = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const int res = hv_clip16((hv_mul24(t[0], D[x]) + hv_mul24(t[1], D[4 + x]) + hv_mul24(t[2], D[8 + x]) + hv_mul24(t[3], D[12 + x]) + 2048) >> 12);
+        const int rc = hv_clip8(res + p[x]);
+        const int dd = (int)S.org[ty + i][tx + x] - rc;
+        sse += hv_mul24(dd, dd);
+        rc4 |= (unsigned)rc << (8 * x);
+    }
+    sse += hv_shfl_xor(sse, 1);
+    sse += hv_shfl_xor(sse, 2);
+    if (ok) {
+        *(HV_LDSP unsigned *)&S.nxn_rec[m][i * 4] = rc4;
+        if (i == 0) { S.nxn_sse[m] = sse; S.nxn_last[m] = last < 0 ? 0 : last; S.nxn_sig[m] = last >= 0; }
+    }
+    WAVE_SYNC();
+}
+/* a helper wavefront of the NxN chain (cluster of four): for each of the CU's four 4x4 blocks, when the chain has laid out the
+   reference samples, the block trials of its 16 modes */
+static HDN void hv_nxn_helper(int q, HvCu cu, int h) {
+    HvLds &S = HV_S;
+    q = hv_uni(q); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x); h = hv_uni(h);
+    const int lane = hv_tid() & 63, m = 16 * h + (lane >> 2);
+    for (int s = 0; s < 4; s++) {
+        while (hv_poll(&S.nxq_go) <= s) hv_spin_pause();
+        hv_tu4_quad(S, q, cu.y + (s >> 1) * 4, cu.x + (s & 1) * 4, m, m < HEVCE_NMODES);
+        HV_FENCE_RELEASE();
+        if (lane == 0) hv_atomic_inc(&S.nxq_done);
+    }
+}
+
 /* NxN job (8x8 CU only): per 4x4 sub-block choose the mode with a fresh coder and fresh contexts  [ref :1499-1528] */
 template <bool FAST>
-static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c70) {
+static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c70, int helpers) {
     HvLds &S = HV_S;
     HvLds::Level &L = S.lv[0];
     q = hv_uni(q); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x);
@@ -1674,7 +1809,12 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
             S.nxn_bord[lane] = (u8)v;
         }
         WAVE_SYNC();
-        if (lane < HEVCE_NMODES) {
+        if (hv_uni(helpers)) {
+            /* three helper wavefronts do the block trials, four lanes per mode (hv_nxn_helper); wait for them */
+            HV_FENCE_RELEASE();
+            if (lane == 0) hv_flag_set(&S.nxq_go, s + 1);
+            while (hv_poll(&S.nxq_done) < 3 * (s + 1)) hv_spin_pause();
+        } else if (lane < HEVCE_NMODES) {
             int last;
             const int sse = hv_tu4_lane(S, q, S.nxn_bord, S.nxn_line[lane], cu.y + oy, cu.x + ox, lane, (HV_LDSP short *)S.nxn_lev[lane], (HV_LDSP u8 *)S.nxn_rec[lane], last);
             S.nxn_sse[lane] = sse; S.nxn_last[lane] = last < 0 ? 0 : last; S.nxn_sig[lane] = last >= 0;
@@ -1887,7 +2027,7 @@ static HD void hv_level_begin(HvLds &S, const HvCu cu) {
     }
     if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = 0; L.tlen[tid] = 0; }
     if (n == 8) for (int k = tid; k < 8 * 8; k += HV_NTHREADS) (&S.nxn_crec[0][0])[k] = 0;
-    if (n == 8 && tid == 0) { S.nxn_busy = 1; S.l0_active = 71; S.c70_done = 0; }
+    if (n == 8 && tid == 0) { S.nxn_busy = 1; S.l0_active = 71; S.c70_done = 0; S.nxq_go = 0; S.nxq_done = 0; }
 }
 
 /* chunks per slot of the candidates a wavefront is binarising: rows of HEVCE_TOKEN_SLOTS + 2 bytes, row 0 = candidate t0, in
@@ -2440,6 +2580,7 @@ static HDN void hv_wr_engine(const HevceImageDesc &im_, int cw, int budget) {
    The schedule is static and wave-uniform (SGPRs): no lane-dependent control flow may surround the jobs (wave shuffles). */
 #define HV_JOBT(slot, call) call
 static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q);
+static HDN void hv_nxn_helper(int q, HvCu cu, int h);
 static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m, int ctu, int wr_on, int cl) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
     const int wv = hv_uni(wave);
@@ -2450,8 +2591,8 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         /* the NxN chain; it also writes the token stream, slot list and engine state of its outcome, candidate 70, and
            clears S.nxn_busy shortly before its end */
         HV_GLOBAL u16 *c70 = (HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3) + (size_t)70 * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0;
-        if (fast) hv_job_nxn<true>(wave, lane, q, c8, c70);
-        else hv_job_nxn<false>(wave, lane, q, c8, c70);
+        if (fast) hv_job_nxn<true>(wave, lane, q, c8, c70, hv_uni(cl) == 2);
+        else hv_job_nxn<false>(wave, lane, q, c8, c70, 0);
         return;
     }
     if (wv == 4) {
@@ -2465,6 +2606,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     }
     if (hv_uni(cl) == 2) {                                       /* cluster of 4: this CU's block jobs and candidates 0..69 are another workgroup's */
         if (wv == 5) hv_c70_rider((HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3) + (size_t)70 * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0, q);
+        if (wv >= 1 && wv <= 3) hv_nxn_helper(q, c8, wv - 1);      /* the NxN chain's block trials, 16 modes each */
         return;
     }
     const int w1 = wv < 4 ? wv - 1 : wv - 2;                     /* work slot 0..5 */
