@@ -70,7 +70,7 @@ typedef struct HevceRes {      /* parent workgroup -> analysis workgroup: the be
     int32_t pad_[2];
     uint8_t ctx[104];          /* contexts after it */
 } HevceRes;
-typedef struct HevceCluster { HevceMsg msg[3]; HevceRes res[3]; int32_t error; int32_t size; int32_t pad_[2]; } HevceCluster;   /* mailboxes: 16x16, 32x32, 8x8 (4 workgroups only) */
+typedef struct HevceCluster { HevceMsg msg[3]; HevceRes res[4]; int32_t error; int32_t size; int32_t pad_[2]; } HevceCluster;   /* mailboxes: 16x16, 32x32, 8x8 (4 / 5 workgroups); res[3]: the second 8x8 workgroup's answer (5) */
 
 /* one image of a batch, as the kernel sees it (all pointers are device pointers) */
 typedef struct HevceImageDesc {

@@ -24,9 +24,11 @@
 #define HV_NOUNROLL
 static inline unsigned hv_ldg_u32(const unsigned *p) { return *p; }
 void emu_yield(void);
-static inline void hv_publish_fence() { }
-static inline void hv_st_release(int *p, int v) { *p = v; }
-static inline int  hv_ld_acquire(const int *p) { return *p; }
+static inline void hv_publish_fence(int) { }
+static inline void hv_acquire_fence(int) { }
+static inline void hv_st_flag(int *p, int v) { *p = v; }
+static inline int  hv_ld_flag(const int *p) { return *p; }
+static inline int  hv_xcc_id() { return 0; }
 static inline void hv_spin_pause() { emu_yield(); }           /* lets the other workgroup's fibers run */
 static inline unsigned long long hv_realtime() { static unsigned long long t; return t += 1; }
 static inline unsigned hv_perm(unsigned a, unsigned b, unsigned sel) {
@@ -97,12 +99,22 @@ template <typename T> static HD T *hv_uni_ptr(T *p) {
     const unsigned long long a = (unsigned long long)p;
     return (T *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a));
 }
-/* cluster mode: hand-off between two workgroups through HBM.  Payload first (plain stores by any thread), hv_publish_fence() by
-   every thread that stored, a workgroup barrier, then ONE thread release-stores the sequence word; the consumer acquire-loads it
-   (agent scope: L2 write-back / invalidate where the workgroups sit on different XCDs) and only then reads the payload. */
-static HD void hv_publish_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
-static HD void hv_st_release(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-static HD int  hv_ld_acquire(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+/* cluster mode: hand-off between workgroups through HBM.  Payload first (plain stores by any thread), hv_publish_fence() by every
+   thread that stored, a workgroup barrier, then ONE thread stores the sequence word; the consumer polls it with loads that
+   bypass its L1 (relaxed, agent scope: no cache maintenance per poll), and when it has the value it wants, hv_acquire_fence().
+   Two flavours of the fences.  HEAVY: agent-scope release / acquire -- on this multi-XCD part an L2 write-back and an L2
+   invalidate, what the memory model asks for between arbitrary workgroups.  LIGHT, when both workgroups are known to sit on the
+   SAME XCD (they then share the L2, and the L1s are write-through): the producer only waits until its stores have left the
+   compute unit, the consumer reads the payload with L1-bypassing loads (hv_ldg_*); no L2 maintenance at all.  Which one applies
+   is decided at run time from the XCC_ID hardware register of the workgroups involved (HvLds::cl_light). */
+static HD void hv_publish_fence(int light) {
+    if (light) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
+static HD void hv_acquire_fence(int light) { if (!light) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+static HD void hv_st_flag(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static HD int  hv_ld_flag(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static HD int  hv_xcc_id() { int v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 15; }
 static HD void hv_spin_pause() { __builtin_amdgcn_s_sleep(8); }
 static HD unsigned long long hv_realtime() { return __builtin_amdgcn_s_memrealtime(); }   /* 100 MHz */
 static HD unsigned hv_ldg_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   /* read at the L2: never a stale L1 line */
@@ -147,6 +159,10 @@ static HD unsigned hv_ldg_u32(const unsigned *p) { return __hip_atomic_load(p, _
 typedef unsigned char  u8;
 typedef unsigned short u16;
 typedef unsigned long long u64;
+/* loads of what ANOTHER workgroup has written (cluster mode): through hv_ldg_u32, i.e. at the L2, never a stale L1 line */
+static HD int hv_ldc_i32(const int32_t *p) { return (int)hv_ldg_u32((const unsigned *)p); }
+static HD int hv_ldc_u8(const u8 *p) { const unsigned long long a = (unsigned long long)p; return (int)((hv_ldg_u32((const unsigned *)(a & ~3ull)) >> ((a & 3) << 3)) & 0xff); }
+static HD int hv_ldc_i16(const short *p) { const unsigned long long a = (unsigned long long)p; return (int)(short)(hv_ldg_u32((const unsigned *)(a & ~3ull)) >> ((a & 2) << 3)); }
 
 /* --------------------------------------------------------------------------------------------- */
 /* compile-time tables                                                                             */
@@ -262,6 +278,7 @@ struct alignas(16) HvLds {
     /* control */
     int cl_seq[3];                                          /* cluster mode: messages sent (chain workgroup) / answered (parent workgroup) per mailbox */
     int cl_pick, cl_fail;                                   /* parent workgroup: the mailbox to serve next (-1 exit); a hand-off timed out */
+    int cl_light, cl_ok;                                    /* all partners share this workgroup's XCD (light hand-offs, see hv_publish_fence); chain workgroup: answer slots whose sender said so */
     int exact;                                              /* 1: EXACT engines (the reference's bit counts by construction); 0: FAST (see hv_fengine_chunk) */
     int poison;                                             /* FAST: this CTU's decisions may differ from the reference's: 1 = NxN winner, 2 = the writer says so */
     int wr_done;                                            /* CTUs the writer has finished */
@@ -2719,15 +2736,18 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
     const int kindw = w < 35 ? 0 : (w < 70 ? 1 : 2);
     for (int p = tid; p < n * n; p += HV_NTHREADS) {
         const int yy = p / n, xx = p % n;
-        S.rec[cu.y + yy + 1][cu.x + xx + HV_RX] = (kindw == 2) ? S.nxn_crec[yy][xx] : grec[w * 1024 + p];
+        /* cluster mode: the winner's samples / levels were written by another workgroup: read at the L2 (hv_ldc_*) */
+        S.rec[cu.y + yy + 1][cu.x + xx + HV_RX] = (kindw == 2) ? S.nxn_crec[yy][xx] : (u8)(cl ? hv_ldc_u8((const u8 *)(grec + w * 1024 + p)) : grec[w * 1024 + p]);
         int lv;
         if (kindw == 0) {
-            lv = glev[w * 1024 + hv_scan_idx(S, cu.lg, hv_scan_kind(n, w), yy, xx)];
+            const int at = w * 1024 + hv_scan_idx(S, cu.lg, hv_scan_kind(n, w), yy, xx);
+            lv = cl ? hv_ldc_i16((const short *)(glev + at)) : glev[at];
         } else {
             const int h = n >> 1, s = (yy >= h) * 2 + (xx >= h);
             const int md = kindw == 1 ? w - 35 : S.nxn_modes[s];
             const int si = hv_scan_idx(S, cu.lg - 1, hv_scan_kind(h, md), yy & (h - 1), xx & (h - 1));
-            lv = kindw == 1 ? glev[w * 1024 + s * h * h + si] : S.nxn_bestlev[s][si];
+            const int at = w * 1024 + s * h * h + si;
+            lv = kindw == 1 ? (cl ? hv_ldc_i16((const short *)(glev + at)) : glev[at]) : S.nxn_bestlev[s][si];
         }
         rec->lev[cu.y + yy][cu.x + xx] = (short)lv;
     }
@@ -2872,10 +2892,10 @@ static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q) {
 /* --------------------------------------------------------------------------------------------- */
 #define HV_CL_BOX(lvl) (((lvl) + 2) % 3)                    /* mailbox of a CU level: 16x16 -> 0, 32x32 -> 1, 8x8 -> 2 */
 #define HV_CL_TIMEOUT 3000000000ull                          /* 30 s of the 100 MHz clock */
-static HD int hv_cl_wait(const int *seq, int want, int *fail) {   /* one thread */
+static HD int hv_cl_wait(const int *seq, int want, int *fail, int light) {   /* one thread */
     const unsigned long long t0 = hv_realtime();
     for (;;) {
-        if (hv_ld_acquire(seq) == want) return 1;
+        if (hv_ld_flag(seq) == want) { hv_acquire_fence(light); return 1; }
         if (hv_realtime() - t0 > HV_CL_TIMEOUT) { *fail = 1; return 0; }
         hv_spin_pause();
     }
@@ -2893,21 +2913,41 @@ static HD void hv_cl_send(HvLds &S, const HevceImageDesc &im, const HvCu cu, int
         m->L = cu.L; m->LB = cu.LB; m->A = cu.A; m->AR = cu.AR;
     }
     if (tid < HEVCE_NCTXP) m->ctx[tid] = S.ent_ctx[cu.lvl][tid];
-    hv_publish_fence();
+    if (tid == 0) m->pad_ = hv_xcc_id();                           /* where this workgroup sits: the receiver may take the light path if it sits there too */
+    hv_publish_fence(S.cl_light);
     BLOCK_SYNC();
-    if (tid == 0) { const int s = S.cl_seq[b] + 1; S.cl_seq[b] = s; hv_st_release(&m->seq, s); }
+    if (tid == 0) { const int s = S.cl_seq[b] + 1; S.cl_seq[b] = s; hv_st_flag(&m->seq, s); }
 }
 /* chain workgroup, at the CU's decision: wait for the answer and make its candidate the only one alive of the level.  All threads. */
 static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu) {
     const int tid = hv_tid(), b = HV_CL_BOX(cu.lvl);
     HvLds::Level &L = S.lv[cu.lvl];
-    const HevceRes *r = &im.cluster->res[b];
-    if (tid == 0) { if (!hv_cl_wait(&r->seq, S.cl_seq[b], &S.cl_fail)) im.cluster->error = 1; }
+    const int size = im.cluster->size, two = cu.lvl == 0 && size >= 5;   /* clusters of five: candidates 0..34 and 35..69 of an 8x8 CU come from a workgroup each */
+    if (tid == 0) {
+        if (!hv_cl_wait(&im.cluster->res[b].seq, S.cl_seq[b], &S.cl_fail, S.cl_light)) im.cluster->error = 1;
+        if (two && !hv_cl_wait(&im.cluster->res[3].seq, S.cl_seq[b], &S.cl_fail, S.cl_light)) im.cluster->error = 1;
+    }
     BLOCK_SYNC();
-    const int w = hv_min(hv_max(r->winner, 0), 69);
-    if (tid < HV_TL) L.tdead[tid] = tid != w && !(cu.lvl == 0 && tid == 70);   /* 8x8: the NxN candidate is the chain workgroup's own */
-    if (tid == 0) { L.tcost[w] = r->cost; L.tsse[w] = r->sse; L.tregs[w] = S.ent[cu.lvl]; L.tregs[w].range = r->range; L.tregs[w].nbits = r->nbits; L.tnlog[w] = 0; L.tpos[w] = -1; }
-    if (tid < HEVCE_NCTXP) L.tctx[tid][w] = r->ctx[tid];
+    const HevceRes *r = &im.cluster->res[b], *r2 = &im.cluster->res[two ? 3 : b];
+    const int w = hv_min(hv_max(hv_ldc_i32(&r->winner), 0), 69), w2 = hv_min(hv_max(hv_ldc_i32(&r2->winner), 0), 69);
+    if (tid < HV_TL) L.tdead[tid] = tid != w && tid != w2 && !(cu.lvl == 0 && tid == 70);   /* 8x8: the NxN candidate is the chain workgroup's own */
+    if (tid == 0) {
+        L.tcost[w] = hv_ldc_i32(&r->cost); L.tsse[w] = hv_ldc_i32(&r->sse); L.tregs[w] = S.ent[cu.lvl];
+        L.tregs[w].range = hv_ldc_i32(&r->range); L.tregs[w].nbits = hv_ldc_i32(&r->nbits); L.tnlog[w] = 0; L.tpos[w] = -1;
+        /* the senders say whether they share this workgroup's XCD; when all of the cluster's do, hand-offs go the light way */
+        int ok = S.cl_ok | (hv_ldc_i32(&r->pad_[0]) == 1 ? 1 << b : 0) | ((two && hv_ldc_i32(&r2->pad_[0]) == 1) ? 8 : 0);
+        S.cl_ok = ok;
+        const int need = size == 2 ? 3 : size == 3 ? 3 : size == 4 ? 7 : 15;
+        if ((ok & need) == need) S.cl_light = 1;
+    }
+    if (tid < HEVCE_NCTXP) L.tctx[tid][w] = (u8)hv_ldc_u8(&r->ctx[tid]);
+    if (two) {
+        if (tid == 64) {
+            L.tcost[w2] = hv_ldc_i32(&r2->cost); L.tsse[w2] = hv_ldc_i32(&r2->sse); L.tregs[w2] = S.ent[cu.lvl];
+            L.tregs[w2].range = hv_ldc_i32(&r2->range); L.tregs[w2].nbits = hv_ldc_i32(&r2->nbits); L.tnlog[w2] = 0; L.tpos[w2] = -1;
+        }
+        if (tid >= 128 && tid < 128 + HEVCE_NCTXP) L.tctx[tid - 128][w2] = (u8)hv_ldc_u8(&r2->ctx[tid - 128]);
+    }
     BLOCK_SYNC();
 }
 /* the samples of a CU that has just been decided go to the picture's reconstruction at once (the parents of the NEXT CUs read them there) */
@@ -2920,19 +2960,20 @@ static HD void hv_cl_store_rcon(HvLds &S, const HevceImageDesc &im, const HvCu c
 
 /* parent workgroup: one stage of a CU's evaluation.  stage 0: block jobs (step 2 / step 3 of the reference's search for this CU,
    [ref :1420-1432, 1455-1468]), 1: context columns + binarisation, 2: the candidates' engines to their end, arg-min, answer. */
-static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, int stage) {
+static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, int stage, int lo, int hi, int slot) {   /* candidates [lo, hi), answer to res[slot] */
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, wv = hv_uni(wave);
     HvLds::Level &L = S.lv[cu.lvl];
     HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
     HvGLev glev = (HvGLev)scr;
     HvGRec grec = (HvGRec)(scr + HV_TL * 1024 * 2);
     if (stage == 0) {
-        if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = tid < 70 ? 0 : -1; L.tlen[tid] = 0; }   /* candidate 70 (NxN) is not this workgroup's */
+        if (tid < HV_TL) { const int mine = tid >= lo && tid < hi; L.tdead[tid] = !mine; L.tpos[tid] = mine ? 0 : -1; L.tlen[tid] = 0; }   /* candidate 70 (NxN) is never this workgroup's */
         if (tid == 0) L.best_cost = HV_I32MAX;
         if (cu.n == 8) {
-            /* 3 chains (16 modes each) + 5 single blocks (8 modes each): one job per wavefront */
-            if (wv < 3) hv_job_chain<4>(wave, lane, q, cu, wv, glev, grec);
-            else hv_job_single<8>(wave, lane, q, cu, wv - 3, glev, grec);
+            /* 3 chains (16 modes each, candidates 35..69) + 5 single blocks (8 modes each, candidates 0..34): one job per wavefront */
+            const int nchain = hi > 35 ? 3 : 0;
+            if (wv < nchain) hv_job_chain<4>(wave, lane, q, cu, wv, glev, grec);
+            else if (lo < 35 && wv - nchain < 5) hv_job_single<8>(wave, lane, q, cu, wv - nchain, glev, grec);
         } else if (cu.n == 16) {
             /* 5 chains (8 modes each) + 9 single blocks (4 modes each) over 8 wavefronts */
             if (wv < 5) hv_job_chain<8>(wave, lane, q, cu, wv, glev, grec);
@@ -2946,7 +2987,7 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
         }
     } else if (stage == 1) {
         hv_level_contexts(S, im, cu);                            /* ends with a barrier */
-        const int tb = 9 * wv, tc = hv_min(9, 70 - tb);
+        const int per = (hi - lo + 7) >> 3, tb = lo + per * wv, tc = hv_max(hv_min(per, hi - tb), 0);
         hv_bin_own<true>(scr, cu, tb, tc);
     } else {
         hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, 1 << cu.lvl, nullptr, 8, wave);
@@ -2970,12 +3011,12 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
         }
         BLOCK_SYNC();
         const int w = hv_min(hv_max(S.winner, 0), 69);
-        HevceRes *r = &im.cluster->res[HV_CL_BOX(cu.lvl)];
-        if (tid == 0) { r->cost = L.tcost[w]; r->winner = w; r->sse = L.tsse[w]; r->range = L.tregs[w].range; r->nbits = L.tregs[w].nbits - L.tnlog[w]; }
+        HevceRes *r = &im.cluster->res[slot];
+        if (tid == 0) { r->cost = L.tcost[w]; r->winner = w; r->sse = L.tsse[w]; r->range = L.tregs[w].range; r->nbits = L.tregs[w].nbits - L.tnlog[w]; r->pad_[0] = S.cl_light ? 1 : 2; }
         if (tid < HEVCE_NCTXP) r->ctx[tid] = L.tctx[tid][w];
-        hv_publish_fence();                                      /* the answer, and the winner's levels / samples in the level scratch */
+        hv_publish_fence(S.cl_light);                            /* the answer, and the winner's levels / samples in the level scratch */
         BLOCK_SYNC();
-        if (tid == 0) { const int sq = S.cl_seq[HV_CL_BOX(cu.lvl)] + 1; S.cl_seq[HV_CL_BOX(cu.lvl)] = sq; hv_st_release(&r->seq, sq); }
+        if (tid == 0) { const int sq = S.cl_seq[HV_CL_BOX(cu.lvl)] + 1; S.cl_seq[HV_CL_BOX(cu.lvl)] = sq; hv_st_flag(&r->seq, sq); }
     }
     BLOCK_SYNC();
 }
@@ -2984,15 +3025,16 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
 static HD HvCu hv_pw_accept(HvLds &S, const HevceImageDesc &im, int b) {
     const int tid = hv_tid();
     const HevceMsg *m = &im.cluster->msg[b];
-    const int lvl = (b + 1) % 3, ncx = im.W >> 5, ctu = m->ctu;
+    const int lvl = (b + 1) % 3, ncx = im.W >> 5, ctu = hv_ldc_i32(&m->ctu);
     const int y0 = (ctu / ncx) * 32, x0 = (ctu % ncx) * 32;
-    HvCu cu = { m->y, m->x, m->n, 3 + lvl, lvl, m->L, m->LB, m->A, m->AR };
+    HvCu cu = { hv_ldc_i32(&m->y), hv_ldc_i32(&m->x), hv_ldc_i32(&m->n), 3 + lvl, lvl, hv_ldc_i32(&m->L), hv_ldc_i32(&m->LB), hv_ldc_i32(&m->A), hv_ldc_i32(&m->AR) };
     HvLds::Level &L = S.lv[lvl];
     if (tid == 0) {
-        S.ent[lvl].range = m->range; S.ent[lvl].low = 0; S.ent[lvl].nbits = m->nbits; S.ent[lvl].nbytes = 0; S.ent[lvl].bufbyte = 0; S.ent[lvl].zeros = 0; S.ent[lvl].nout = 0; S.ent[lvl].pad = 0;
-        L.split_inc = m->split_inc; L.ml = m->ml; L.ma = m->ma;
+        S.ent[lvl].range = hv_ldc_i32(&m->range); S.ent[lvl].low = 0; S.ent[lvl].nbits = hv_ldc_i32(&m->nbits); S.ent[lvl].nbytes = 0; S.ent[lvl].bufbyte = 0; S.ent[lvl].zeros = 0; S.ent[lvl].nout = 0; S.ent[lvl].pad = 0;
+        L.split_inc = hv_ldc_i32(&m->split_inc); L.ml = hv_ldc_i32(&m->ml); L.ma = hv_ldc_i32(&m->ma);
+        S.cl_light = hv_ldc_i32(&m->pad_) == hv_xcc_id();          /* the chain workgroup sits on this XCD: light hand-offs from now on */
     }
-    if (tid < HEVCE_NCTXP) S.ent_ctx[lvl][tid] = m->ctx[tid];
+    if (tid < HEVCE_NCTXP) S.ent_ctx[lvl][tid] = (u8)hv_ldc_u8(&m->ctx[tid]);
     for (int p = tid; p < 1024; p += HV_NTHREADS) {                 /* source samples, edge-replicated  [ref :1620-1622] */
         const int yy = hv_min(y0 + (p >> 5), im.src_h - 1), xx = hv_min(x0 + (p & 31), im.src_w - 1);
         S.org[p >> 5][p & 31] = im.img[(size_t)yy * (size_t)im.src_stride + xx];
@@ -3000,7 +3042,7 @@ static HD HvCu hv_pw_accept(HvLds &S, const HevceImageDesc &im, int b) {
     for (int p = tid; p < 33 * 65; p += HV_NTHREADS) {              /* rows y0-1 .. y0+31, columns x0-1 .. x0+63 of the reconstruction so far */
         const int r = p / 65, c = p % 65;
         const int yy = hv_min(hv_max(y0 - 1 + r, 0), im.H - 1), xx = hv_min(hv_max(x0 - 1 + c, 0), im.W - 1);
-        S.rec[r][HV_RX - 1 + c] = im.rcon[(size_t)yy * im.W + xx];
+        S.rec[r][HV_RX - 1 + c] = (u8)hv_ldc_u8(im.rcon + (size_t)yy * im.W + xx);
     }
     BLOCK_SYNC();
     return cu;
@@ -3008,17 +3050,22 @@ static HD HvCu hv_pw_accept(HvLds &S, const HevceImageDesc &im, int b) {
 /* The parent workgroup of a picture (cluster mode, second workgroup): it answers the chain workgroup's messages until told to
    exit.  16x16 CUs are answered at once (the chain needs them four rounds later); the 32x32 CU of a CTU, whose answer is due
    at the end of the CTU, is worked on stage by stage in between. */
-static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve) {   /* serve: bit 0 = the 16x16 mailbox, bit 1 = the 32x32 mailbox */
+static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, int lo8, int hi8, int slot8) {   /* serve: bit 0 = the 16x16 mailbox, bit 1 = 32x32, bit 2 = 8x8 (its candidates [lo8, hi8), answered in res[slot8]) */
     const int tid = hv_tid(), q = im.qpd6;
     if (tid == 0) { S.trace = nullptr; S.qlut = im.qlut; }
     BLOCK_SYNC();
     hv_init_tables(S, q, tid);
     hv_set_mode(S, 0, tid);
-    if (tid == 0) { S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_fail = 0; S.cl_pick = 0; }
+    if (tid == 0) { S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_fail = 0; S.cl_pick = 0; S.cl_light = 0; S.cl_ok = 0; }
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
     BLOCK_SYNC();
     HevceCluster *C = im.cluster;
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+    if (tid < 32) S.prof2[tid] = 0;
+    unsigned long long wt_ = __builtin_amdgcn_s_memtime();
+    BLOCK_SYNC();
+#endif
     int stage32 = -1;                                            /* -1: no 32x32 CU in progress */
     HvCu c32 = { 0, 0, 32, 5, 2, 0, 0, 0, 0 };
     for (;;) {
@@ -3026,13 +3073,14 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve) {
             const unsigned long long t0 = hv_realtime();
             int pick = 0;
             for (;;) {
-                if ((serve & 4) && hv_ld_acquire(&C->msg[2].seq) == S.cl_seq[2] + 1) { pick = 4; break; }   /* an 8x8 CU (or the exit message) */
-                if ((serve & 1) && hv_ld_acquire(&C->msg[0].seq) == S.cl_seq[0] + 1) { pick = 1; break; }   /* a 16x16 CU (or the exit message): first */
+                if ((serve & 4) && hv_ld_flag(&C->msg[2].seq) == S.cl_seq[2] + 1) { pick = 4; break; }   /* an 8x8 CU (or the exit message) */
+                if ((serve & 1) && hv_ld_flag(&C->msg[0].seq) == S.cl_seq[0] + 1) { pick = 1; break; }   /* a 16x16 CU (or the exit message): first */
                 if (stage32 >= 0) { pick = 2; break; }                                                   /* the 32x32 CU in progress */
-                if ((serve & 2) && hv_ld_acquire(&C->msg[1].seq) == S.cl_seq[1] + 1) { pick = 3; break; }   /* a new 32x32 CU (or the exit message) */
+                if ((serve & 2) && hv_ld_flag(&C->msg[1].seq) == S.cl_seq[1] + 1) { pick = 3; break; }   /* a new 32x32 CU (or the exit message) */
                 if (hv_realtime() - t0 > HV_CL_TIMEOUT) { pick = -1; C->error = 2; break; }
                 hv_spin_pause();
             }
+            if (pick == 1 || pick == 3 || pick == 4) hv_acquire_fence(S.cl_light);
             S.cl_pick = pick;
         }
         BLOCK_SYNC();
@@ -3041,18 +3089,32 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve) {
         if (pick < 0) break;
         if (pick == 1 || pick == 4) {
             const int b = pick == 1 ? 0 : 2;
-            if (C->msg[b].kind == 2) break;
+            if (hv_ldc_i32(&C->msg[b].kind) == 2) break;
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+            if (tid == 0 && b == 2) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[0] += n_ - wt_; wt_ = n_; S.prof2[5] += 1; }
+#endif
             const HvCu cu = hv_pw_accept(S, im, b);
-            for (int st = 0; st < 3; st++) hv_pw_stage(S, im, cu, st);
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+            if (tid == 0 && b == 2) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[1] += n_ - wt_; wt_ = n_; }
+#endif
+            for (int st = 0; st < 3; st++) {
+                hv_pw_stage(S, im, cu, st, b == 2 ? lo8 : 0, b == 2 ? hi8 : 70, b == 2 ? slot8 : b);
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+                if (tid == 0 && b == 2) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[2 + st] += n_ - wt_; wt_ = n_; }
+#endif
+            }
         } else {
             if (pick == 3) {
-                if (C->msg[1].kind == 2) break;
+                if (hv_ldc_i32(&C->msg[1].kind) == 2) break;
                 c32 = hv_pw_accept(S, im, 1); stage32 = 0;               /* a 16x16 CU served in between reloads the same CTU's samples: harmless */
             }
-            hv_pw_stage(S, im, c32, stage32);
+            hv_pw_stage(S, im, c32, stage32, 0, 70, 1);
             stage32 = stage32 == 2 ? -1 : stage32 + 1;
         }
     }
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+    if (im.trace && (serve & 4) && slot8 == 2 && tid < 8) ((unsigned long long *)im.trace)[80 + tid] = S.prof2[tid];   /* 8x8 worker: wait, accept, stages 0..2, messages */
+#endif
 }
 
 /* the writer does a whole CTU in one go (wavefront 4; the others wait at the caller's barrier) */
@@ -3103,7 +3165,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int force_exact = (im.flags & 1) || !im.payload;      /* without the writer nothing vouches for the FAST decisions */
     const int pk_nxn = (im.flags >> 8) & 0xff, pk_wr = (im.flags >> 16) & 0xff;
     hv_set_mode(S, force_exact, tid);
-    if (tid == 0) { S.poison = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_fail = 0; }
+    if (tid == 0) { S.poison = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_fail = 0; S.cl_light = 0; S.cl_ok = 0; }
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
     BLOCK_SYNC();

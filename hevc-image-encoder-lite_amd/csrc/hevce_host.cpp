@@ -191,7 +191,8 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
         hipDeviceProp_t prop;
         int cus = 0;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
-        j->cluster = !j->device_emit ? 1 : (4 * n <= cus ? 4 : (3 * n <= cus ? 3 : (2 * n <= cus ? 2 : 1)));
+        const int n8 = (n + 7) & ~7;                             /* the grid is padded to eight pictures per role (one cluster = one XCD, hevce_kernel.hip) */
+        j->cluster = !j->device_emit ? 1 : (5 * n8 <= cus ? 5 : (4 * n8 <= cus ? 4 : (3 * n8 <= cus ? 3 : (2 * n8 <= cus ? 2 : 1))));
         if (const char *e = getenv("HEVCE_CLUSTER")) { const int mx = atoi(e); if (mx >= 0 && mx < j->cluster) j->cluster = mx < 1 ? 1 : mx; }
     }
     if (getenv("HEVCE_DUMP")) {

@@ -5,18 +5,23 @@
 
 extern "C" __global__ void __launch_bounds__(HV_NTHREADS, 2)
 hevce_analyse_kernel(const HevceImageDesc *__restrict__ images, int nimages, int cluster) {
-    /* cluster mode: `cluster` (2, 3 or 4) workgroups per picture -- the first walks the picture's chain of decisions, the others
-       evaluate candidates for it: the 16x16 / 32x32 CUs (one workgroup for both levels, or one each), with four also the 8x8 CUs' */
-    const int b = blockIdx.x, pic = cluster > 1 ? b / cluster : b, role = cluster > 1 ? b % cluster : 0;
+    /* cluster mode: `cluster` (2 .. 5) workgroups per picture -- the first walks the picture's chain of decisions, the others
+       evaluate candidates for it: the 16x16 / 32x32 CUs (one workgroup for both levels, or one each), with four also the 8x8 CUs'
+       (five: candidates 0..34 and 35..69 on a workgroup each) */
+    /* the workgroups of a picture get block ids that are equal modulo 8: consecutive ids go round the 8 XCDs, so a cluster sits
+       on one XCD and shares its L2 (hand-offs without L2 maintenance; checked at run time, hevce_device.h hv_publish_fence) */
+    const int b = blockIdx.x, npad = (nimages + 7) & ~7;
+    const int pic = cluster > 1 ? b % npad : b, role = cluster > 1 ? b / npad : 0;
     if (pic >= nimages) return;
     const HevceImageDesc im = images[pic];
     if (role == 0) hv_analyse_image(HV_S, im);
-    else hv_parent_worker(HV_S, im, cluster == 2 ? 3 : (role == 3 ? 4 : role));
+    else if (role >= 3) hv_parent_worker(HV_S, im, 4, (cluster >= 5 && role == 4) ? 35 : 0, (cluster >= 5 && role == 3) ? 35 : 70, role == 4 ? 3 : 2);
+    else hv_parent_worker(HV_S, im, cluster == 2 ? 3 : role, 0, 70, 2);
 }
 
 /* host-side launcher used by hevce_host.cpp: grid = images of the batch (times the cluster size) */
 extern "C" int hevce_launch_analyse(const HevceImageDesc *d_images, int n, int cluster, hipStream_t stream) {
-    hipLaunchKernelGGL(hevce_analyse_kernel, dim3((unsigned)(cluster > 1 ? cluster * n : n)), dim3(HV_NTHREADS), 0, stream, d_images, n, cluster);
+    hipLaunchKernelGGL(hevce_analyse_kernel, dim3((unsigned)(cluster > 1 ? cluster * ((n + 7) & ~7) : n)), dim3(HV_NTHREADS), 0, stream, d_images, n, cluster);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -18,7 +18,7 @@
 void emu_wave_sync(void);
 void emu_block_sync(void);
 extern int  emu_cur;                 /* running fiber = workgroup * 512 + thread id */
-extern int  emu_stage[32][64];       /* shuffle staging, per wave (up to four workgroups) */
+extern int  emu_stage[40][64];       /* shuffle staging, per wave (up to five workgroups) */
 
 #define WAVE_SYNC()  emu_wave_sync()
 #define BLOCK_SYNC() emu_block_sync()

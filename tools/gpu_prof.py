@@ -37,6 +37,9 @@ if kind == "phases":
     names = ["jobs", "-", "split+finish", "arg-min", "commit", "ctx init", "engines", "-"]
     for lvl, nm in enumerate(("8x8", "16x16", "32x32")):
         print(f"  CU {nm:6s}", "  ".join(f"{names[p]} {100.0*prof[lvl,p]/tot:5.1f}%" for p in range(7) if names[p] != "-"))
+    wk = tr[160:176].view(np.uint64).astype(float)
+    if wk[5] > 0:
+        print("  8x8 worker (cluster >= 4), k cycles per message: wait %.1f, accept %.1f, jobs %.1f, contexts+binarise %.1f, engines+answer %.1f" % tuple(wk[i] / wk[5] / 1e3 for i in range(5)))
     print("  NxN chain:", "  ".join(f"{nm} {100.0*p2[i]/tot:5.1f}%" for i, nm in enumerate(("4x4 pipelines", "tokenise", "engine", "select", "tail"))))
 elif kind == "nxn":
     stages = nctu * 64
