@@ -2990,7 +2990,9 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
         const int per = (hi - lo + 7) >> 3, tb = lo + per * wv, tc = hv_max(hv_min(per, hi - tb), 0);
         hv_bin_own<true>(scr, cu, tb, tc);
     } else {
-        hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, 1 << cu.lvl, nullptr, 8, wave);
+        /* four engine wavefronts, one per SIMD (18 candidates each): the loop is one dependent instruction stream, two of them on a
+           SIMD take turns (measured: 8 x 9 lanes 44.8 k cycles per 8x8 CU, 4 x 18 lanes less) */
+        hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, 1 << cu.lvl, nullptr, 4, wave < 4 ? wave : -1);
         BLOCK_SYNC();
         if (wv == 0) {                                           /* arg-min, the later candidate wins ties  [ref :1440, 1476] */
             int bc = HV_I32MAX, bi = -2;
