@@ -2152,8 +2152,11 @@ static HDN void hv_run_engines(HV_GLOBAL u8 *scratch, int q, int mask, int *shar
     const int lane = hv_tid() & 63;
     q = hv_uni(q); mask = hv_uni(mask); nw = hv_uni(nw); ew = hv_uni(ew);
     const int fast = !hv_uni(S.exact);
-    const int per = HV_TL / nw;
-    const int lvl = lane / per, t = (lane % per) * nw + ew;
+    /* nw > 0: `nw` wavefronts share all candidates of the levels in `mask`, this one is number ew.  nw < 0: this wavefront runs
+       the -nw candidates ew, ew + 1, ... of the (one) level in mask, one per lane -- its own, straight after binarising them */
+    const int per = nw > 0 ? HV_TL / nw : HV_TL;
+    const int lvl = nw > 0 ? lane / per : ((mask & 1) ? 0 : (mask & 2) ? 1 : 2);
+    const int t = nw > 0 ? (lane % per) * nw + ew : (lane < -nw ? ew + lane : HV_TL);
     if (ew >= 0 && lvl < 3 && ((mask >> lvl) & 1)) {
         HvLds::Level &L = S.lv[lvl];
         const int ntrials = (lvl == 0) ? 71 : 70;
@@ -2970,10 +2973,20 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
         if (tid < HV_TL) { const int mine = tid >= lo && tid < hi; L.tdead[tid] = !mine; L.tpos[tid] = mine ? 0 : -1; L.tlen[tid] = 0; }   /* candidate 70 (NxN) is never this workgroup's */
         if (tid == 0) L.best_cost = HV_I32MAX;
         if (cu.n == 8) {
-            /* 3 chains (16 modes each, candidates 35..69) + 5 single blocks (8 modes each, candidates 0..34): one job per wavefront */
+            /* 3 chains (16 modes each, candidates 35..69) + 5 single blocks (8 modes each, candidates 0..34): one job per wavefront,
+               and everything that follows for the candidates of that job -- binarisation, engines -- in the same wavefront: nothing
+               depends on another wavefront until the arg-min, so there is no barrier in between (the 8x8 answer is on the chain
+               workgroup's critical path) */
+            hv_level_contexts(S, im, cu);                        /* ends with a barrier */
             const int nchain = hi > 35 ? 3 : 0;
-            if (wv < nchain) hv_job_chain<4>(wave, lane, q, cu, wv, glev, grec);
-            else if (lo < 35 && wv - nchain < 5) hv_job_single<8>(wave, lane, q, cu, wv - nchain, glev, grec);
+            int tb = -1, tc = 0;
+            if (wv < nchain) { hv_job_chain<4>(wave, lane, q, cu, wv, glev, grec); tb = 35 + 16 * wv; tc = hv_min(16, 70 - tb); }
+            else if (lo < 35 && wv - nchain < 5) { hv_job_single<8>(wave, lane, q, cu, wv - nchain, glev, grec); tb = 8 * (wv - nchain); tc = hv_min(8, 35 - tb); }
+            if (tb >= 0) {
+                hv_bin_own<true>(scr, cu, tb, tc);
+                WAVE_SYNC();
+                hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, 1, nullptr, -tc, tb);
+            }
         } else if (cu.n == 16) {
             /* 5 chains (8 modes each) + 9 single blocks (4 modes each) over 8 wavefronts */
             if (wv < 5) hv_job_chain<8>(wave, lane, q, cu, wv, glev, grec);
@@ -2986,13 +2999,14 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
             else for (int j = wv - 1; j < 18; j += 7) hv_job_single<32>(wave, lane, q, cu, j, glev, grec);
         }
     } else if (stage == 1) {
+        if (cu.n == 8) return;                                   /* done in stage 0 */
         hv_level_contexts(S, im, cu);                            /* ends with a barrier */
         const int per = (hi - lo + 7) >> 3, tb = lo + per * wv, tc = hv_max(hv_min(per, hi - tb), 0);
         hv_bin_own<true>(scr, cu, tb, tc);
     } else {
         /* four engine wavefronts, one per SIMD (18 candidates each): the loop is one dependent instruction stream, two of them on a
            SIMD take turns (measured: 8 x 9 lanes 44.8 k cycles per 8x8 CU, 4 x 18 lanes less) */
-        hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, 1 << cu.lvl, nullptr, 4, wave < 4 ? wave : -1);
+        if (cu.n != 8) hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, 1 << cu.lvl, nullptr, 4, wave < 4 ? wave : -1);
         BLOCK_SYNC();
         if (wv == 0) {                                           /* arg-min, the later candidate wins ties  [ref :1440, 1476] */
             int bc = HV_I32MAX, bi = -2;
