@@ -272,6 +272,7 @@ struct alignas(16) HvLds {
     };
     int   nxn_ntok[35];                                     /* per mode of the current 4x4 block: tokens | bypass bins << 8 | bits << 20 */
     int   c70_len, c70_byp;                                 /* tokens / bypass bins of candidate 70's stream so far */
+    int   nxq_mag, nxn_magn[35];                            /* cluster of four: stages whose greater / remainder tokens a helper has written (second half of the nxn_tok rows); per mode tokens | bypass bins << 8 */
     int   nxq_go, nxq_done;                                 /* cluster of four: 4x4 blocks whose reference samples are laid out; helper wavefronts done, in all */
     int   c70_done, c70_seg[4], c70_pat;                    /* FAST: stages whose winner's tokens are in the stream (5: header known too); per stage offset | tokens << 16 | cbf << 31; the CU header's four prev_intra_luma_pred_flags */
     u8    nxn_ctx[HEVCE_NCTXP][HV_TL];                      /* context columns of the NxN chain's 35 modes (fresh per 4x4 block) */
@@ -749,7 +750,9 @@ template <typename LP> static HD void hv_cg_load(const HvLds &S, HvCg &g, LP lev
     for (int i = 0; i < 8; i++) m8 = (__builtin_popcount(m8) > 8) ? (m8 & (m8 - 1)) : m8;
     g.g1own = (bigm & m8) != 0;
 }
-template <typename WR> static HD int hv_cg_emit(const HvLds &S, WR &w, const HvCg &g, int g1) {
+/* in two parts, so that two wavefronts can share a group's binarisation (the NxN chain with helpers): part 1 = the
+   coded_sub_block_flag and the significance flags, part 2 = greater1 / greater2 flags, signs, remaining magnitudes */
+template <typename WR> static HD void hv_cg_emit_sig(const HvLds &S, WR &w, const HvCg &g) {
     if (g.coded) {
         const int first_cg = g.first_cg, at_last_cg = g.at_last_cg, cgs = g.cgs, start = g.start;
         const unsigned nzm = g.nzm;
@@ -764,6 +767,14 @@ template <typename WR> static HD int hv_cg_emit(const HvLds &S, WR &w, const HvC
                 hv_emit(w, HV_CT(CX_SIG + tab[ii], (nzm >> ii) & 1), on);
             }
             hv_tok_checkpoint(w);                                  /* <= 17 tokens so far */
+        }
+    }
+}
+template <typename WR> static HD void hv_cg_emit_mag(const HvLds &S, WR &w, const HvCg &g, int g1) {
+    if (g.coded) {
+        const int first_cg = g.first_cg, cgs = g.cgs;
+        const unsigned nzm = g.nzm;
+        if (cgs || first_cg) {
             const int nz = __builtin_popcount(nzm);
             /* greater1 flags of the first eight non-zero levels, one greater2 flag; sign bits in the same order */
             const int set4 = (first_cg ? 0 : 8) + (g1 ? 4 : 0), set1 = (first_cg ? 0 : 2) + (g1 ? 1 : 0);
@@ -800,6 +811,10 @@ template <typename WR> static HD int hv_cg_emit(const HvLds &S, WR &w, const HvC
             }
         }
     }
+}
+template <typename WR> static HD int hv_cg_emit(const HvLds &S, WR &w, const HvCg &g, int g1) {
+    hv_cg_emit_sig(S, w, g);
+    hv_cg_emit_mag(S, w, g, g1);
     hv_tok_checkpoint(w);
     return hv_tok_finish(w);
 }
@@ -1788,6 +1803,25 @@ static HDN void hv_nxn_helper(int q, HvCu cu, int h) {
         hv_tu4_quad(S, q, cu.y + (s >> 1) * 4, cu.x + (s & 1) * 4, m, m < HEVCE_NMODES);
         HV_FENCE_RELEASE();
         if (lane == 0) hv_atomic_inc(&S.nxq_done);
+        if (h == 0) {
+            /* the first helper goes on with half of the binarisation, lane = mode: greater1 / greater2 flags and the bypass-bin
+               count of every mode's block, into the second half of the mode's token row, while the chain wavefront writes the
+               prefix and significance tokens and starts its engines on them */
+            while (hv_poll(&S.nxq_done) < 3 * (s + 1)) hv_spin_pause();
+            if (lane < HEVCE_NMODES) {
+                HV_LDSP u16 *tk = (HV_LDSP u16 *)S.nxn_tok[lane] + 72;
+                HvTokW<HV_LDSP u16 *, true> wm = { tk, 0, 0 };
+                HvCg g;
+                hv_cg_load(S, g, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, hv_scan_kind(4, lane), 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0), 1);
+                hv_cg_emit_mag(S, wm, g, 0);
+#pragma unroll
+                for (int i = 0; i < 8; i++) tk[HV_SLOT_TOK0 + wm.n + i] = (u16)HV_TOK_NOPF;
+                S.nxn_magn[lane] = wm.n | (wm.byp << 8);
+            }
+            HV_FENCE_RELEASE();
+            WAVE_SYNC();
+            if (lane == 0) hv_flag_set(&S.nxq_mag, s + 1);
+        }
     }
 }
 
@@ -1855,7 +1889,9 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
             HvTokW<HV_LDSP u16 *, FAST> wb = { tk + na, 0, 0 };
             HvCg g;
             hv_cg_load(S, g, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0), 1);
-            const int nb = hv_cg_emit(S, wb, g, 0);
+            int nb;
+            if (FAST && hv_uni(helpers)) { hv_cg_emit_sig(S, wb, g); nb = wb.n; }   /* the greater / remainder part: a helper wavefront, meanwhile (hv_nxn_helper) */
+            else nb = hv_cg_emit(S, wb, g, 0);
 #pragma unroll
             for (int i = 0; i < 8; i++) tk[HV_SLOT_TOK0 + na + nb + i] = (u16)(FAST ? HV_TOK_NOPF : HV_TOK_NOP);
             HV_PROF2(S, 1);
@@ -1866,6 +1902,12 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
             if constexpr (FAST) {
                 HvFCod c = { 510, 23 };
                 hv_fengine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb);
+                if (hv_uni(helpers)) {
+                    while (hv_poll(&S.nxq_mag) <= s) hv_spin_pause();
+                    const int mg = S.nxn_magn[lane], nm = mg & 0xff;
+                    hv_fengine(S, c, cx, (const HV_LDSP HvChunk *)(tk + 72 + HV_SLOT_TOK0), nm);
+                    nb += nm; wb.byp += mg >> 8;
+                }
                 bits = 23 - c.nbits + wa.byp + wb.byp;
             } else {
                 HvCod c;
@@ -1899,9 +1941,10 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
             const int pk = S.nxn_ntok[w];
             const int off = S.c70_len, cbf = S.nxn_sig[w], n = cbf ? (pk & 0xff) : 0;
             const HV_LDSP u16 *src = (const HV_LDSP u16 *)S.nxn_tok[w] + HV_SLOT_TOK0;
+            const int nm = (FAST && hv_uni(helpers)) ? (S.nxn_magn[w] & 0xff) : 0, na1 = n - nm;   /* with helpers the tokens are in two pieces */
             if (lane == 0) c70[off] = (u16)HV_CT(CX_YCBF, cbf);
-            if (lane < n) c70[off + 1 + lane] = src[lane];
-            if (lane + 64 < n) c70[off + 65 + lane] = src[lane + 64];
+            if (lane < n) c70[off + 1 + lane] = lane < na1 ? src[lane] : src[72 + lane - na1];
+            if (lane + 64 < n) c70[off + 65 + lane] = lane + 64 < na1 ? src[lane + 64] : src[72 + lane + 64 - na1];
             if constexpr (FAST) {
                 /* kept for hv_verify_nxn: the winner's levels, what the tokeniser was given, the bit count it was chosen with */
                 const int blk = (((cu.y >> 3) * 4 + (cu.x >> 3)) << 2) | s;
@@ -2044,7 +2087,7 @@ static HD void hv_level_begin(HvLds &S, const HvCu cu) {
     }
     if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = 0; L.tlen[tid] = 0; }
     if (n == 8) for (int k = tid; k < 8 * 8; k += HV_NTHREADS) (&S.nxn_crec[0][0])[k] = 0;
-    if (n == 8 && tid == 0) { S.nxn_busy = 1; S.l0_active = 71; S.c70_done = 0; S.nxq_go = 0; S.nxq_done = 0; }
+    if (n == 8 && tid == 0) { S.nxn_busy = 1; S.l0_active = 71; S.c70_done = 0; S.nxq_go = 0; S.nxq_done = 0; S.nxq_mag = 0; }
 }
 
 /* chunks per slot of the candidates a wavefront is binarising: rows of HEVCE_TOKEN_SLOTS + 2 bytes, row 0 = candidate t0, in
@@ -2862,13 +2905,12 @@ static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q) {
         while (hv_poll(&S.c70_done) <= s) hv_spin_pause();
         const int seg = hv_uni(S.c70_seg[s]), off = seg & 0xffff, n = (seg >> 16) & 0x7fff, cbf = (seg >> 31) & 1;
         for (int t = lane; t < n; t += 64) stage[t] = (u16)(hv_ldg_u32((const unsigned *)(c70 + ((off + 1 + t) & ~1))) >> (((off + 1 + t) & 1) << 4));
+        if (lane < 16) stage[n + lane] = (u16)HV_TOK_NOPF;          /* whole chunks, and one more for the engine's prefetch */
         WAVE_SYNC();
         if (act) {
+            *HV_CX(HV_CT_PAD) = HV_PADCV;
             hv_fbin(S, c, HV_CX(CX_YCBF), cbf);                                                             /* [ref :1038-1043] */
-            HV_NOUNROLL for (int t = 0; t < n; t++) {
-                const int tok = stage[t];
-                hv_fbin(S, c, cx + (tok & 0x1fff), (tok >> 14) & 1);
-            }
+            hv_fengine(S, c, cx, (const HV_LDSP HvChunk *)stage, n);   /* the same bins in all sixteen lanes, each with its own range and contexts */
         }
         WAVE_SYNC();
     }
