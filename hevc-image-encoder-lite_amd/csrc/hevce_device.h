@@ -627,7 +627,7 @@ static HD int hv_last_min(int g) { return g < 4 ? g : (2 + (g & 1)) << ((g >> 1)
 
 /* TU header slot: cbf_luma (unless the caller is the NxN sub-search, which codes bare residuals) and the position of
    the last significant coefficient   [ref :1038-1087, 1192].  Straight-line like the CU header (<= 25 tokens). */
-template <int MAXG = 9, typename WR> static HD int hv_tokenize_tu(const HvLds &S, WR &w, int n, int lg, int kind_scan, int with_cbf, int cbf_ctx, int cbf, int last) {   /* MAXG: largest prefix group the caller's block sizes can reach (4x4: 3) */
+template <int MAXG = 9, typename WR> static HD void hv_tokenize_tu_body(const HvLds &S, WR &w, int n, int lg, int kind_scan, int with_cbf, int cbf_ctx, int cbf, int last) {   /* MAXG: largest prefix group the caller's block sizes can reach (4x4: 3) */
     hv_emit(w, HV_CT(cbf_ctx, cbf), with_cbf);
     const int on0 = cbf || !with_cbf;
     int gy, gx, iy, ix;
@@ -650,6 +650,9 @@ template <int MAXG = 9, typename WR> static HD int hv_tokenize_tu(const HvLds &S
 #pragma unroll
     for (int i = 2; i >= 0; i--) if (MAXG > 3) hv_emit_b(w, (ty >> i) & 1, 1, on0 && i < ny);
     hv_tok_checkpoint(w);
+}
+template <int MAXG = 9, typename WR> static HD int hv_tokenize_tu(const HvLds &S, WR &w, int n, int lg, int kind_scan, int with_cbf, int cbf_ctx, int cbf, int last) {
+    hv_tokenize_tu_body<MAXG>(S, w, n, lg, kind_scan, with_cbf, cbf_ctx, cbf, last);
     return hv_tok_finish(w);
 }
 
@@ -2123,6 +2126,17 @@ static HD void hv_bin_group(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL
     const int g1 = before ? (int)((bg1 >> (63 - hv_clzll(before))) & 1) : 0;
     if (!valid) return;
     HV_LDSP u8 &sh = hv_cnt(cn, t, 1 + tu * (1 + ncgt) + 1 + r);
+    if (tn == 4) {
+        /* a 4x4 block is one group: its header (cbf_luma, last position) goes into the group's slot, in front of the group's
+           tokens, and the header slot stays empty -- one padded slot less per block for the engines to walk (TU-split 8x8
+           candidates: five slots instead of nine; they are the longest of an 8x8 CU's candidates) */
+        HvTokRingT<FAST> w4 = hv_tok_ring<FAST>(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * 2 + 1) * HV_SLOT);
+        hv_tokenize_tu_body<3>(S, w4, 4, 2, hv_scan_kind(4, t - 35), 1, CX_YCBF, cbf, L.tinfo[t][tu].last);
+        sh = (u8)hv_cg_emit(S, w4, g, g1);
+        hv_cnt(cn, t, 1 + tu * 2) = 0;
+        if (FAST) hv_atomic_add(&L.tnlog[t], w4.byp);
+        return;
+    }
     if (!cbf) { sh = 0; return; }
     HvTokRingT<FAST> w = hv_tok_ring<FAST>(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt) + 1 + r) * HV_SLOT);
     sh = (u8)hv_cg_emit(S, w, g, g1);
@@ -2282,7 +2296,7 @@ static HDN void hv_bin_own(HV_GLOBAL u8 *scr, HvCu cu, int tb, int tc) {
     HV_BINT(0);
     for (int j = lane; j < tc * 4; j += 64) {
         const int t = tb + (j >> 2), tu = j & 3;
-        if (t >= 35 || tu == 0) hv_bin_tu_header<FAST>(S, L, cu, gtok, cn, t, tu);
+        if (t >= 35 ? cu.n > 8 : tu == 0) hv_bin_tu_header<FAST>(S, L, cu, gtok, cn, t, tu);   /* 4x4 blocks: header inside the group's slot (hv_bin_group) */
     }
     HV_BINT(1);
     for (int j = lane; j < tc; j += 64) hv_bin_cu_header<FAST>(S, L, cu, gtok, cn, tb + j);
