@@ -281,6 +281,7 @@ struct alignas(16) HvLds {
     int cl_pick, cl_fail;                                   /* parent workgroup: the mailbox to serve next (-1 exit); a hand-off timed out */
     int cl_light, cl_ok;                                    /* all partners share this workgroup's XCD (light hand-offs, see hv_publish_fence); chain workgroup: answer slots whose sender said so */
     int exact;                                              /* 1: EXACT engines (the reference's bit counts by construction); 0: FAST (see hv_fengine_chunk) */
+    int nxv_pend, poison_prev;                              /* cluster of four: the previous CTU's NxN winners wait (copied into slist2) to be verified during this CTU; they failed */
     int poison;                                             /* FAST: this CTU's decisions may differ from the reference's: 1 = NxN winner, 2 = the writer says so */
     int wr_done;                                            /* CTUs the writer has finished */
     struct Snap { HevceCoderRegs com; u8 com_ctx[HEVCE_NCTXP]; u8 map_cu8[8], map_pm8[8], rec_col[32], line_cu[8]; } snap[2];   /* what a CTU starts from, [ctu & 1] */
@@ -823,11 +824,6 @@ template <typename WR> static HD int hv_cg_emit(const HvLds &S, WR &w, const HvC
 }
 
 #define HV_CX(i) (cx + (i) * HV_TL)
-static HD int hv_chunk_get(const HvChunk &c, int i) {
-    const unsigned lo = (i & 4) ? c[2] : c[0], hi = (i & 4) ? c[3] : c[1];
-    const unsigned d = (i & 2) ? hi : lo;
-    return (int)((d >> ((i & 1) << 4)) & 0xffffu);
-}
 /* The arithmetic engine of a candidate  [ref CABACputBin / CABACputBins :899-933]: resumable -- the coder registers and the
    position in the token stream are all the state there is.  cx = the candidate's context column (&tctx[0][candidate]).
    All lanes of a wavefront run the loop in lockstep; one iteration = one token through the same straight-line code for
@@ -2048,22 +2044,31 @@ static HD void hv_emit(HvTokExec &w, int tok, int on) {
 }
 static HD void hv_tok_checkpoint(HvTokExec &) { }
 static HD int  hv_tok_finish(HvTokExec &) { return 0; }
-static HDN void hv_verify_nxn(int lane) {
+struct HvNxv { short lev[64][16]; u16 info[64]; short bits[64]; };   /* a copy of the nxv_* arrays (deferred verification) */
+static HD HV_LDSP HvNxv *hv_nxv_copy(HvLds &S) {                 /* lives in slist2: the 32x32 level's slot lists are unused in cluster mode */
+    return (HV_LDSP HvNxv *)((HV_LDSP u8 *)&S.slist2[0][0] + ((16 - ((unsigned)(unsigned long long)&S.slist2[0][0] & 15)) & 15));
+}
+static HDN void hv_verify_nxn(int lane, int deferred) {
     HvLds &S = HV_S;
-    u8 *cx = &S.nxn_ctx[0][lane];
+    deferred = hv_uni(deferred);
+    /* deferred (cluster of four, a spare wavefront during the NEXT CTU's first round): the copy of the winners, and context
+       columns of the 16x16 level, which is another workgroup's business in cluster mode */
+    HV_LDSP HvNxv *V = hv_nxv_copy(S);
+    u8 *cx = deferred ? &S.lv[1].tctx[0][lane] : &S.nxn_ctx[0][lane];
     for (int k = 0; k < 3; k++) { *HV_CX(CX_LASTX + k) = S.ctx_fresh[CX_LASTX + k]; *HV_CX(CX_LASTY + k) = S.ctx_fresh[CX_LASTY + k]; }
     for (int k = 0; k < 9; k++) *HV_CX(CX_SIG + k) = S.ctx_fresh[CX_SIG + k];
     for (int k = 0; k < 4; k++) *HV_CX(CX_ONE + k) = S.ctx_fresh[CX_ONE + k];
     *HV_CX(CX_ABS) = S.ctx_fresh[CX_ABS];
-    const int info = S.nxv_info[lane], last = info & 15, ks = (info >> 4) & 3, sig = (info >> 6) & 1;
+    const int info = deferred ? V->info[lane] : S.nxv_info[lane], last = info & 15, ks = (info >> 4) & 3, sig = (info >> 6) & 1;
+    const int want = deferred ? V->bits[lane] : S.nxv_bits[lane];
     HvTokExec w;
     w.S = &S; w.cx = cx; w.n = 0;
     hv_cod_fresh(w.c);
     hv_tokenize_tu<3>(S, w, 4, 2, ks, 0, 0, 1, last);
     HvCg g;
-    hv_cg_load(S, g, (const HV_LDSP short *)S.nxv_lev[lane], 4, 2, ks, 0, last, (u64)sig, 1);
+    hv_cg_load(S, g, deferred ? (const HV_LDSP short *)V->lev[lane] : (const HV_LDSP short *)S.nxv_lev[lane], 4, 2, ks, 0, last, (u64)sig, 1);
     hv_cg_emit(S, w, g, 0);
-    if (hv_cod_bits(w.c) != S.nxv_bits[lane]) S.poison = 1;
+    if (hv_cod_bits(w.c) != want) { if (deferred) S.poison_prev = 1; else S.poison = 1; }
 }
 
 /* --------------------------------------------------------------------------------------------- */
@@ -2307,86 +2312,12 @@ static HDN void hv_bin_own(HV_GLOBAL u8 *scr, HvCu cu, int tb, int tc) {
 }
 
 /* --------------------------------------------------------------------------------------------- */
-/* The stream writer: ONE lane of wavefront 4 turns the decision record of the PREVIOUS CTU into the bytes of  */
-/* the slice data while the other wavefronts analyse the next one -- the reference's byte-emitting coder and syntax writers  */
-/* applied to the chosen syntax only  [ref CABACput :821-832, CABACupdate :859-879, CABACputBin(s) :899-933, putTerminate    */
-/* :882-896, CABACfinish :840-856, syntax :943-1340].  Plain serial code: with one active lane a branch costs nothing.        */
-/* It is sliced by 8x8 position: slice r (z-order) writes the CU whose origin is that position, so that it fits in the shadow */
-/* of the NxN chain of the analysis round r.                                                                                  */
+/* The stream writer: wavefront 4 turns the decision record of the PREVIOUS CTU into the bytes of the slice data    */
+/* while the other wavefronts analyse the next one -- the reference's syntax writers and byte-emitting coder applied to the      */
+/* chosen syntax only  [ref CABACput :821-832, CABACupdate :859-879, CABACputBin(s) :899-933, putTerminate :882-896,             */
+/* CABACfinish :840-856, syntax :943-1340].  hv_wr_tokenise: the whole CTU binarised in one lane-parallel pass (lane = 4x4         */
+/* position); hv_wr_engine: the bins through the exact coder, a budgeted slice per analysis round, as wave-uniform scalar code.   */
 /* --------------------------------------------------------------------------------------------- */
-struct HvWr { int range; unsigned low; int nbits, pending, held, zeros, n, epb; HV_GLOBAL u8 *out; int exact; };
-static HD HvWr hv_wr_load(const HvLds &S, const HevceImageDesc &im) {
-    HvWr w = { S.wr.range, S.wr.low, S.wr.nbits, S.wr.nbytes, S.wr.bufbyte, S.wr.zeros, S.wr.nout, S.wr_epb, (HV_GLOBAL u8 *)im.payload, S.exact };
-    return w;
-}
-static HD void hv_wr_store(HvLds &S, const HvWr &w) {
-    S.wr.range = w.range; S.wr.low = w.low; S.wr.nbits = w.nbits; S.wr.nbytes = w.pending; S.wr.bufbyte = w.held; S.wr.zeros = w.zeros; S.wr.nout = w.n; S.wr.pad = 0;
-    S.wr_epb = w.epb;
-}
-static HD void hv_wr_put(HvWr &w, int byte) {                                                              /* [ref :821-832] */
-    byte &= 0xff;
-    if (w.zeros >= 2 && byte <= 3) { if (w.out) w.out[w.n] = 3; w.n++; w.zeros = 0; w.epb++; }
-    if (w.out) w.out[w.n] = (u8)byte;
-    w.n++;
-    w.zeros = byte ? 0 : w.zeros + 1;
-}
-static HD void hv_wr_carry(HvWr &w) {                                                                      /* [ref :859-879] */
-    if (w.nbits >= 12) return;
-    const int lead = (int)(w.low >> (24 - w.nbits));
-    w.nbits += 8;
-    w.low &= 0xffffffffu >> w.nbits;
-    if (lead == 0xff) { w.pending++; return; }
-    if (w.pending > 0) {
-        const int c = lead >> 8, fill = (0xff + c) & 0xff;
-        hv_wr_put(w, w.held + c);
-        w.held = lead & 0xff;
-        for (; w.pending > 1; w.pending--) hv_wr_put(w, fill);
-    } else { w.pending = 1; w.held = lead; }                     /* first byte ever: stored unmasked, as the reference does */
-}
-static HD void hv_wr_bin(HvLds &S, HvWr &w, u8 *cp, int bin) {                                              /* [ref :914-933] */
-    /* two dependent LDS reads per bin -- the context byte, then the engines' table entry for it (whichever table the workgroup's
-       mode has built, hv_set_mode): the writer is bound by their latency, not by instructions */
-    const int v = *cp;
-    unsigned l4, nx;
-    int islps;
-    if (w.exact) { l4 = S.ctab[v][0]; const unsigned e = S.ctab[v][1]; islps = (bin ^ v) & 1; nx = (e >> (islps ? 0 : 8)) & 0xff; }
-    else { l4 = S.ctab2[(v << 1) | bin][0]; const unsigned e = S.ctab2[(v << 1) | bin][1]; islps = (int)(e >> 8); nx = e & 0xff; }
-    const int lps = (int)((l4 >> (((w.range >> 6) & 3) << 3)) & 0xff);
-    const int rm = w.range - lps;
-    *cp = (u8)nx;
-    if (islps) {
-        const int sh = hv_clz_nz((unsigned)lps) - 23;
-        w.low = (w.low + (unsigned)rm) << sh;
-        w.range = lps << sh;
-        w.nbits -= sh;
-    } else if (rm < 256) { w.low <<= 1; w.range = rm << 1; w.nbits--; }
-    else w.range = rm;
-    hv_wr_carry(w);
-}
-static HD void hv_wr_bypass(HvWr &w, int bins, int len) {                                                  /* [ref :899-911] */
-    bins &= (1 << len) - 1;
-    while (len > 0) {
-        const int n = hv_min(len, 8);
-        len -= n;
-        w.low = (w.low << n) + (unsigned)w.range * (unsigned)((bins >> len) & ((1 << n) - 1));
-        w.nbits -= n;
-        hv_wr_carry(w);
-    }
-}
-static HD void hv_wr_terminate(HvWr &w, int bin) {                                                         /* [ref :882-896] */
-    w.range -= 2;
-    if (bin) { w.low = (w.low + (unsigned)w.range) << 7; w.range = 256; w.nbits -= 7; }
-    else if (w.range < 256) { w.low <<= 1; w.range <<= 1; w.nbits--; }
-    hv_wr_carry(w);
-}
-static HD void hv_wr_finish(HvWr &w) {                                                                     /* [ref :840-856] */
-    int fill = 0;
-    if ((w.low >> (32 - w.nbits)) > 0) { hv_wr_put(w, w.held + 1); w.low -= 1u << (32 - w.nbits); }
-    else { if (w.pending > 0) hv_wr_put(w, w.held); fill = 0xff; }
-    for (; w.pending > 1; w.pending--) hv_wr_put(w, fill);
-    const int tail = (int)((w.low >> 8) << w.nbits);
-    hv_wr_put(w, tail >> 16); hv_wr_put(w, tail >> 8); hv_wr_put(w, tail);
-}
 /* neighbour context of the CTU being written, with the reference's line-buffer semantics  [ref :1369-1373, 1595-1600, 1634-1637]:
    CU size 32 outside the picture; mode DC outside the picture and across a CTU-row boundary */
 static HD int hv_wr_cu_left(const HvLds &S, int L, int y, int x)  { return x > 0 ? 8 << (S.wr_rec.info[y >> 2][(x >> 2) - 1] & HEVCE_INFO_LOG2_MASK) : (L ? 8 << (S.wr_linfo[y >> 2] & HEVCE_INFO_LOG2_MASK) : 32); }
@@ -2684,6 +2615,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     if (hv_uni(cl) == 2) {                                       /* cluster of 4: this CU's block jobs and candidates 0..69 are another workgroup's */
         if (wv == 5) hv_c70_rider((HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3) + (size_t)70 * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0, q);
         if (wv >= 1 && wv <= 3) hv_nxn_helper(q, c8, wv - 1);      /* the NxN chain's block trials, 16 modes each */
+        if (wv == 6 && k16 == 0 && m == 0 && hv_uni(S.nxv_pend)) hv_verify_nxn(lane, 1);   /* the previous CTU's NxN winners, off the critical path */
         return;
     }
     const int w1 = wv < 4 ? wv - 1 : wv - 2;                     /* work slot 0..5 */
@@ -3237,7 +3169,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int force_exact = (im.flags & 1) || !im.payload;      /* without the writer nothing vouches for the FAST decisions */
     const int pk_nxn = (im.flags >> 8) & 0xff, pk_wr = (im.flags >> 16) & 0xff;
     hv_set_mode(S, force_exact, tid);
-    if (tid == 0) { S.poison = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_fail = 0; S.cl_light = 0; S.cl_ok = 0; }
+    if (tid == 0) { S.poison = 0; S.nxv_pend = 0; S.poison_prev = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_fail = 0; S.cl_light = 0; S.cl_ok = 0; }
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
     BLOCK_SYNC();
@@ -3351,17 +3283,28 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
 
         }
         BLOCK_SYNC();
-        /* ---- is everything decided so far the reference's decision?  (FAST only; see hv_fengine_chunk) ---- */
-        if (!tail && !exact && (tid >> 6) == 4) hv_verify_nxn(tid & 63);
+        /* ---- is everything decided so far the reference's decision?  (FAST only; see hv_fengine_chunk) ----
+           The NxN winners of this CTU: verified here (wavefront 4, the others wait), or -- cluster of four, where wavefronts are to
+           spare -- copied and verified during the next CTU's first round (hv_jobs_phase); then a failure rolls back one CTU more,
+           like the writer's. */
+        const int pend = hv_uni(S.nxv_pend);                     /* the previous CTU's winners were deferred to this round */
+        const int defer = cl8 && !tail;
+        if (!tail && !exact) {
+            if (defer) { HV_LDSP HvNxv *V = hv_nxv_copy(S); for (int i = tid; i < (int)(sizeof(HvNxv) / 4); i += HV_NTHREADS) ((HV_LDSP unsigned *)V)[i] = ((const HV_LDSP unsigned *)&S.nxv_lev[0][0])[i]; }
+            else if ((tid >> 6) == 4) hv_verify_nxn(tid & 63, 0);
+        }
+        if (tail && pend && (tid >> 6) == 4) hv_verify_nxn(tid & 63, 1);    /* the last CTU's: nothing left to overlap them with */
         BLOCK_SYNC();
         const int chk_range = tail ? S.com.range : S.snap[ctu & 1].com.range;     /* the analysis' range where the writer now stands */
         const int bad_wr = wr_on && S.wr.range != chk_range;                       /* must never happen: counted, and healed like a poisoned CTU */
-        const int p_wr = wr_on && (S.wr_epb > 0 || bad_wr || (pk_wr && (ctu - 1) % pk_wr == pk_wr - 1 && redone != ctu - 1));
-        const int p_nxn = !tail && !exact && (S.poison || (pk_nxn && ctu % pk_nxn == pk_nxn - 1 && redone != ctu));
+        const int p_prev = pend && (S.poison_prev || (pk_nxn && (ctu - 1) % pk_nxn == pk_nxn - 1 && redone != ctu - 1));
+        const int p_wr = p_prev || (wr_on && (S.wr_epb > 0 || bad_wr || (pk_wr && (ctu - 1) % pk_wr == pk_wr - 1 && redone != ctu - 1)));
+        const int p_nxn = !tail && !exact && !defer && (S.poison || (pk_nxn && ctu % pk_nxn == pk_nxn - 1 && redone != ctu));
         BLOCK_SYNC();
+        if (tid == 0) { S.nxv_pend = (defer && !exact && !p_wr && !p_nxn) ? 1 : 0; S.poison_prev = 0; }
         if (p_wr || p_nxn) {
-            /* back to the start of the poisoned CTU (the previous one if the writer objected), EXACT this time; the EXACT coder
-               continues from the writer's registers at that point */
+            /* back to the start of the poisoned CTU (the previous one if the writer or the deferred verification objected), EXACT this
+               time; the EXACT coder continues from the writer's registers at that point */
             n_redo++; n_bad += bad_wr;
             if (p_wr) {
                 ctu--;

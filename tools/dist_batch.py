@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2] on N GPUs of one node: a batch of independent pictures, dealt out over
 the ranks by CTU count (hevc-image-encoder-lite_amd/sharding.py), every rank encoding its shard in launches of at most 256
-pictures, no collective on the data path; rank 0 collects (index, length, SHA-256) of every stream.
+pictures, no collective on the data path; rank 0 collects (index, length, SHA-256) of every stream
+(hevc-image-encoder-lite_amd/distributed.py: shard_batch, encode_shard, gather_streams -- the functions bench.py uses).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/dist_batch.py [n] [h] [w]
 (N = 1: plain `python tools/dist_batch.py ...`).  Synthetic G2-16 pictures, seed 0x1234ABCD + index; --unique K generates only
 K different pictures (index mod K) to keep the host side short."""
@@ -21,33 +22,33 @@ def main():
     import torch.distributed as dist
     import hevce_pkg, hevce_workload as wl
     hevce = hevce_pkg.load()
-    sharding = importlib.import_module(hevce.__name__ + ".sharding")
+    D = importlib.import_module(hevce.__name__ + ".distributed")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         torch.cuda.set_device(local)
     sizes = [(h, w)] * n
-    mine = sharding.partition_lpt(sizes, world)[rank]
+    mine = D.shard_batch(sizes, world)[rank]
     pics = {k: wl.gen_g2(h, w, 16, seed=0x1234ABCD + k) for k in sorted({i % unique for i in mine})}
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    out = []
-    for base in range(0, len(mine), 256):                       # one workgroup per compute unit and launch
-        part = mine[base:base + 256]
+
+    def enc(part):                                              # one launch: one workgroup per picture (clusters when few)
         with hevce.Job([sizes[i] for i in part], 2, device=local) as job:
             for j, i in enumerate(part):
                 job.upload(j, pics[i % unique])
             job.run()
-            out += [(i, len(job.stream(j)), hashlib.sha256(job.stream(j)).hexdigest()) for j, i in enumerate(part)]
+            return [job.stream(j) for j in range(len(part))]
+    streams = D.encode_shard(enc, mine, per_launch=256)
+    out = [(i, len(streams[i]), hashlib.sha256(streams[i]).hexdigest()) for i in mine]
     elapsed = time.perf_counter() - t0
     if world > 1:
         e = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local))
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         elapsed = float(e.item())
-        table = [None] * world
-        dist.all_gather_object(table, out)
-        out = [x for part in table for x in part]
+        got = D.gather_streams([json.dumps(out).encode()], device=torch.device("cuda", local))
+        out = [tuple(x) for part in got for x in json.loads(part[0].decode())] if rank == 0 else out
     if rank == 0:
         out.sort()
         ok = [i for i, _, _ in out] == list(range(n)) and all(s == out[i % unique][2] for i, _, s in out)
