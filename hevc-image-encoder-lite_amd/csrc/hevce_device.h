@@ -30,6 +30,7 @@ static inline void hv_st_flag(int *p, int v) { *p = v; }
 static inline int  hv_ld_flag(const int *p) { return *p; }
 static inline int  hv_xcc_id() { return 0; }
 static inline void hv_spin_pause() { emu_yield(); }           /* lets the other workgroup's fibers run */
+static inline void hv_spin_short() { emu_yield(); }
 static inline unsigned long long hv_realtime() { static unsigned long long t; return t += 1; }
 static inline unsigned hv_perm(unsigned a, unsigned b, unsigned sel) {
     const unsigned long long src = ((unsigned long long)a << 32) | b;
@@ -115,7 +116,8 @@ static HD void hv_acquire_fence(int light) { if (!light) __builtin_amdgcn_fence(
 static HD void hv_st_flag(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static HD int  hv_ld_flag(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static HD int  hv_xcc_id() { int v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 15; }
-static HD void hv_spin_pause() { __builtin_amdgcn_s_sleep(8); }
+static HD void hv_spin_pause() { __builtin_amdgcn_s_sleep(2); }   /* between two polls of a word in HBM: 128 cycles (a hand-off is on the critical path) */
+static HD void hv_spin_short() { __builtin_amdgcn_s_sleep(1); }   /* between two polls of an LDS flag */
 static HD unsigned long long hv_realtime() { return __builtin_amdgcn_s_memrealtime(); }   /* 100 MHz */
 static HD unsigned hv_ldg_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   /* read at the L2: never a stale L1 line */
 #endif
@@ -1798,7 +1800,7 @@ static HDN void hv_nxn_helper(int q, HvCu cu, int h) {
     q = hv_uni(q); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x); h = hv_uni(h);
     const int lane = hv_tid() & 63, m = 16 * h + (lane >> 2);
     for (int s = 0; s < 4; s++) {
-        while (hv_poll(&S.nxq_go) <= s) hv_spin_pause();
+        while (hv_poll(&S.nxq_go) <= s) hv_spin_short();
         hv_tu4_quad(S, q, cu.y + (s >> 1) * 4, cu.x + (s & 1) * 4, m, m < HEVCE_NMODES);
         HV_FENCE_RELEASE();
         if (lane == 0) hv_atomic_inc(&S.nxq_done);
@@ -1806,7 +1808,7 @@ static HDN void hv_nxn_helper(int q, HvCu cu, int h) {
             /* the first helper goes on with half of the binarisation, lane = mode: greater1 / greater2 flags and the bypass-bin
                count of every mode's block, into the second half of the mode's token row, while the chain wavefront writes the
                prefix and significance tokens and starts its engines on them */
-            while (hv_poll(&S.nxq_done) < 3 * (s + 1)) hv_spin_pause();
+            while (hv_poll(&S.nxq_done) < 3 * (s + 1)) hv_spin_short();
             if (lane < HEVCE_NMODES) {
                 HV_LDSP u16 *tk = (HV_LDSP u16 *)S.nxn_tok[lane] + 72;
                 HvTokW<HV_LDSP u16 *, true> wm = { tk, 0, 0 };
@@ -1863,7 +1865,7 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
             /* three helper wavefronts do the block trials, four lanes per mode (hv_nxn_helper); wait for them */
             HV_FENCE_RELEASE();
             if (lane == 0) hv_flag_set(&S.nxq_go, s + 1);
-            while (hv_poll(&S.nxq_done) < 3 * (s + 1)) hv_spin_pause();
+            while (hv_poll(&S.nxq_done) < 3 * (s + 1)) hv_spin_short();
         } else if (lane < HEVCE_NMODES) {
             int last;
             const int sse = hv_tu4_lane(S, q, S.nxn_bord, S.nxn_line[lane], cu.y + oy, cu.x + ox, lane, (HV_LDSP short *)S.nxn_lev[lane], (HV_LDSP u8 *)S.nxn_rec[lane], last);
@@ -1902,7 +1904,7 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
                 HvFCod c = { 510, 23 };
                 hv_fengine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb);
                 if (hv_uni(helpers)) {
-                    while (hv_poll(&S.nxq_mag) <= s) hv_spin_pause();
+                    while (hv_poll(&S.nxq_mag) <= s) hv_spin_short();
                     const int mg = S.nxn_magn[lane], nm = mg & 0xff;
                     hv_fengine(S, c, cx, (const HV_LDSP HvChunk *)(tk + 72 + HV_SLOT_TOK0), nm);
                     nb += nm; wb.byp += mg >> 8;
@@ -2848,7 +2850,7 @@ static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q) {
         hv_fbin(S, c, HV_CX(CX_UVCBF), 0);
     }
     for (int s = 0; s < 4; s++) {
-        while (hv_poll(&S.c70_done) <= s) hv_spin_pause();
+        while (hv_poll(&S.c70_done) <= s) hv_spin_short();
         const int seg = hv_uni(S.c70_seg[s]), off = seg & 0xffff, n = (seg >> 16) & 0x7fff, cbf = (seg >> 31) & 1;
         for (int t = lane; t < n; t += 64) stage[t] = (u16)(hv_ldg_u32((const unsigned *)(c70 + ((off + 1 + t) & ~1))) >> (((off + 1 + t) & 1) << 4));
         if (lane < 16) stage[n + lane] = (u16)HV_TOK_NOPF;          /* whole chunks, and one more for the engine's prefetch */
@@ -2860,7 +2862,7 @@ static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q) {
         }
         WAVE_SYNC();
     }
-    while (hv_poll(&S.c70_done) < 5) hv_spin_pause();
+    while (hv_poll(&S.c70_done) < 5) hv_spin_short();
     const int pat = hv_uni(S.c70_pat) & 15;
     if (lane == pat) {
         const int byp = L.tnlog[70];
