@@ -64,6 +64,7 @@ def lib():
         L.hevce_job_use_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.hevce_job_set_flags.argtypes = [C.c_void_p, C.c_int]
         L.hevce_job_stats.argtypes = [C.c_void_p, C.c_int, _i32p]
+        L.hevce_job_cluster.argtypes = [C.c_void_p, _i32p]
         for f in ("hevce_job_run", "hevce_job_launch", "hevce_job_finish"):
             getattr(L, f).argtypes = [C.c_void_p]
         L.hevce_job_stream.restype = _u8p
@@ -201,6 +202,12 @@ class Job:
     def set_flags(self, flags):
         """tests: bit 0 exact coders throughout; bits 8-15 / 16-23 forced re-analysis periods (include/hevce_mi355x.h)"""
         _check(lib().hevce_job_set_flags(self._h, int(flags)), "hevce_job_set_flags")
+
+    def cluster(self):
+        """(workgroups per picture of the next launch, launches repeated without clusters after a timed-out hand-off)"""
+        fb = C.c_int(0)
+        k = lib().hevce_job_cluster(self._h, C.byref(fb))
+        return int(k), int(fb.value)
 
     def stats(self, i=0):
         """(CTUs analysed twice, coder consistency failures) of image i in the last run"""

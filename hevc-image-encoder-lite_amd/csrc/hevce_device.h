@@ -2885,11 +2885,11 @@ static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q) {
 /* --------------------------------------------------------------------------------------------- */
 #define HV_CL_BOX(lvl) (((lvl) + 2) % 3)                    /* mailbox of a CU level: 16x16 -> 0, 32x32 -> 1, 8x8 -> 2 */
 #define HV_CL_TIMEOUT 3000000000ull                          /* 30 s of the 100 MHz clock */
-static HD int hv_cl_wait(const int *seq, int want, int *fail, int light) {   /* one thread */
+static HD int hv_cl_wait(const int *seq, int want, int *fail, int light, unsigned long long timeout = HV_CL_TIMEOUT) {   /* one thread */
     const unsigned long long t0 = hv_realtime();
     for (;;) {
         if (hv_ld_flag(seq) == want) { hv_acquire_fence(light); return 1; }
-        if (hv_realtime() - t0 > HV_CL_TIMEOUT) { *fail = 1; return 0; }
+        if (*fail || hv_realtime() - t0 > timeout) { *fail = 1; return 0; }   /* after one failure the picture is lost anyway: no more waiting */
         hv_spin_pause();
     }
 }
@@ -2917,8 +2917,9 @@ static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu) 
     HvLds::Level &L = S.lv[cu.lvl];
     const int size = im.cluster->size, two = cu.lvl == 0 && size >= 5;   /* clusters of five: candidates 0..34 and 35..69 of an 8x8 CU come from a workgroup each */
     if (tid == 0) {
-        if (!hv_cl_wait(&im.cluster->res[b].seq, S.cl_seq[b], &S.cl_fail, S.cl_light)) im.cluster->error = 1;
-        if (two && !hv_cl_wait(&im.cluster->res[3].seq, S.cl_seq[b], &S.cl_fail, S.cl_light)) im.cluster->error = 1;
+        const unsigned long long to = (im.flags & 4) ? 100000ull : HV_CL_TIMEOUT;   /* test hook (flag bit 2): the workers have left, give up after 1 ms */
+        if (!hv_cl_wait(&im.cluster->res[b].seq, S.cl_seq[b], &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
+        if (two && !hv_cl_wait(&im.cluster->res[3].seq, S.cl_seq[b], &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
     }
     BLOCK_SYNC();
     const HevceRes *r = &im.cluster->res[b], *r2 = &im.cluster->res[two ? 3 : b];
@@ -3067,6 +3068,7 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
     hv_init_sigtab(S, tid);
     BLOCK_SYNC();
     HevceCluster *C = im.cluster;
+    if (im.flags & 4) return;                                    /* test hook: a worker that never answers (as if it had not become resident) */
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     if (tid < 32) S.prof2[tid] = 0;
     unsigned long long wt_ = __builtin_amdgcn_s_memtime();

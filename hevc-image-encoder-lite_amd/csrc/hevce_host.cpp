@@ -129,6 +129,7 @@ struct hevce_job {
     uint8_t *h_streams = nullptr; size_t h_streams_bytes = 0;   /* pinned: header + slice data of every picture, back to back; grows on demand */
     bool device_emit = true;         /* the kernel emits the slice data itself; HEVCE_HOST_WRITER=1: replay the records on the host instead */
     int flags = 0;                   /* HevceImageDesc.flags (tests: HEVCE_FLAGS) */
+    int cluster_fallbacks = 0;       /* launches repeated without clusters after a hand-off timed out */
     int cluster = 1;                 /* workgroups per picture (hevce_device.h cluster mode): as many (<= 3) as fit the device side by side */
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
@@ -279,6 +280,11 @@ int hevce_job_set_flags(hevce_job *j, int flags) {
     j->flags = flags; j->desc_dirty = true;
     return 0;
 }
+int hevce_job_cluster(hevce_job *j, int *fallbacks) {
+    if (!j) return fail("hevce_job_cluster: null job");
+    if (fallbacks) *fallbacks = j->cluster_fallbacks;
+    return (j->cluster > 1 && !(j->flags & 2)) ? j->cluster : 1;
+}
 int hevce_job_stats(hevce_job *j, int i, int *out2) {
     if (!j || i < 0 || i >= j->n || !out2) return fail("hevce_job_stats: bad arguments");
     HIPCHK(hipSetDevice(j->device));
@@ -361,7 +367,7 @@ int hevce_job_finish(hevce_job *j) {
                 /* a hand-off between a picture's two workgroups timed out (they were not resident side by side): once more, one
                    workgroup per picture */
                 fprintf(stderr, "hevce_mi355x: cluster hand-off timed out (image %d); encoding again without clusters\n", i);
-                j->cluster = 1; j->desc_dirty = true;
+                j->cluster = 1; j->desc_dirty = true; j->cluster_fallbacks++;
                 if (hevce_job_launch(j) != 0) return -1;
                 return hevce_job_finish(j);
             }

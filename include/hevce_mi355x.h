@@ -88,6 +88,9 @@ int  hevce_job_timings(hevce_job *job, float *kernel_ms, float *d2h_ms, float *w
    per picture even when two would fit (no cluster mode), bits 8-15 / 16-23 = force a re-analysis every k-th CTU through either
    detection path. */
 int  hevce_job_set_flags(hevce_job *job, int flags);
+/* workgroups per picture the next launch uses (1 = no clusters); *fallbacks (may be NULL) = launches that had to be repeated without
+   clusters because a hand-off timed out.  Flag bit 2 (tests) makes the cluster's workers leave at once, which exercises that path. */
+int  hevce_job_cluster(hevce_job *job, int *fallbacks);
 int  hevce_job_stats(hevce_job *job, int i, int *out2);
 
 /* diagnostics and function-level test hooks */

@@ -247,3 +247,19 @@ def test_job_is_ordered_behind_the_callers_stream():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "gpu_stream_order.py")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "stream order ok" in p.stdout, p.stdout + p.stderr
+
+
+def test_cluster_falls_back_when_its_workers_do_not_answer(hevce, orc):
+    """cluster mode needs a picture's workgroups resident side by side; when a hand-off times out the picture is flagged and the host
+    encodes the launch again with one workgroup per picture.  Flag bit 2 makes the workers leave at once (and shortens the wait)."""
+    import hevce_workload as wl
+    img = wl.gen_g2(64, 96, 16, seed=77)
+    want, wrc = orc.encode(img, 2)
+    with hevce.Job([img.shape], 2) as job:
+        if job.cluster()[0] < 2:
+            pytest.skip("the device is too small for clusters")
+        job.set_flags(4)
+        job.upload(0, img)
+        job.run()
+        assert job.stream(0) == want and np.array_equal(job.rcon(0), wrc)
+        assert job.cluster() == (1, 1)
