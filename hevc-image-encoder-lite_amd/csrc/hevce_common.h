@@ -95,11 +95,18 @@ typedef struct HevceImageDesc {
     int32_t        pad_;
 } HevceImageDesc;
 
-#define HEVCE_WRTOK_BYTES   (3 * 64 * HEVCE_TOKEN_SLOT_WORDS * 2)            /* CU header, block header, group slot per 4x4 position */
+#define HEVCE_WRTOK_SLOT_WORDS 128
+#define HEVCE_WRTOK_BYTES   (3 * 64 * HEVCE_WRTOK_SLOT_WORDS * 2)            /* CU header, block header, group slot per 4x4 position */
 #define HEVCE_TRIALS        72                               /* 35 + 35 + 1 (+1 pad) trial slots */
-#define HEVCE_TOKEN_SLOT_WORDS 128                           /* 16-bit words per bin-token slot */
+#define HEVCE_TOKEN_SLOT_WORDS 128                           /* 16-bit words per bin-token slot, EXACT streams (context bins + bypass chunks) */
+#define HEVCE_FTOKEN_SLOT_WORDS 32                           /* FAST streams: context bins only, at most 31 per slot (hevce_device.h hv_tok_finish) */
 #define HEVCE_TOKEN_SLOTS      70                            /* slots per trial: CU header + block headers + 4x4 groups */
 #define HEVCE_SINK_WORDS       8192                          /* finished-byte records per trial between two replays (a 32x32 CU: < 6200 bytes in all) */
-#define HEVCE_SCRATCH_LEVEL_BYTES (HEVCE_TRIALS * 1024 * 3 + HEVCE_TRIALS * HEVCE_TOKEN_SLOTS * HEVCE_TOKEN_SLOT_WORDS * 2 + HEVCE_TRIALS * HEVCE_SINK_WORDS * 2)
+/* one CU level's trial scratch: levels + samples | FAST token slots | EXACT token slots | EXACT byte sinks.  The FAST analysis touches
+   only the first two (dense: 64-byte slots), which keeps the picture's rewritten lines inside the L2 (write traffic) */
+#define HEVCE_SCR_FTOK   (HEVCE_TRIALS * 1024 * 3)
+#define HEVCE_SCR_XTOK   (HEVCE_SCR_FTOK + HEVCE_TRIALS * HEVCE_TOKEN_SLOTS * HEVCE_FTOKEN_SLOT_WORDS * 2)
+#define HEVCE_SCR_SINK   (HEVCE_SCR_XTOK + HEVCE_TRIALS * HEVCE_TOKEN_SLOTS * HEVCE_TOKEN_SLOT_WORDS * 2)
+#define HEVCE_SCRATCH_LEVEL_BYTES (HEVCE_SCR_SINK + HEVCE_TRIALS * HEVCE_SINK_WORDS * 2)
 #define HEVCE_SCRATCH_BYTES (3 * HEVCE_SCRATCH_LEVEL_BYTES)   /* one set per CU level: 8x8, 16x16, 32x32 candidates coexist */
                                                              /* int16 levels + u8 reconstruction + bin tokens per trial */

@@ -516,6 +516,7 @@ static HD void hv_terminate(HvCod &c, int bin) {              /* [ref :882-896] 
 /*   non-empty slots in order (list in LDS), so no contiguous copy of the stream is ever made.                */
 /* --------------------------------------------------------------------------------------------- */
 #define HV_SLOT        HEVCE_TOKEN_SLOT_WORDS /* 16-bit words per slot: header + up to 127 tokens (a group needs <= 109) */
+#define HV_WSLOT       HEVCE_WRTOK_SLOT_WORDS /* the stream writer's slots: exact tokens, always the full size */
 #define HV_SLOTS_TRIAL HEVCE_TOKEN_SLOTS                     /* CU header + at most 4 x (1 + 16) or 1 + 64 block/group slots            */
 #define HV_TOK_BYP     0x8000
 #define HV_TOK_NOP     HV_TOK_BYP
@@ -529,6 +530,14 @@ static HD void hv_terminate(HvCod &c, int bin) {              /* [ref :882-896] 
 
 template <typename P, bool FAST = false> struct HvTokW { P p; int n; int byp; enum { fast = FAST }; };
 #define HV_SLOT_TOK0 8                      /* tokens start 16 bytes into the slot so that chunks of 8 load as one dwordx4 */
+/* trial slots in HBM: EXACT streams in 256-byte slots (header + <= 109 tokens), FAST streams -- context bins only, <= 31 per slot:
+   CU header <= 10, block header <= 19, 4x4 group <= 26, 4x4 block with its header <= 31 -- in 64-byte slots of their own region, so
+   that the lines a FAST analysis rewrites CTU after CTU are dense and stay in the L2 (hevce_common.h HEVCE_SCR_*) */
+template <bool F> struct HvSlotGeo { enum { words = F ? HEVCE_FTOKEN_SLOT_WORDS : HEVCE_TOKEN_SLOT_WORDS, tok0 = F ? 0 : HV_SLOT_TOK0, base = F ? HEVCE_SCR_FTOK : HEVCE_SCR_XTOK }; };
+static HD HV_GLOBAL u16 *hv_c70_area(HV_GLOBAL u8 *s0, int fast) {   /* candidate 70 (the NxN outcome): one contiguous stream in its trial's slots */
+    return fast ? (HV_GLOBAL u16 *)(s0 + HEVCE_SCR_FTOK) + (size_t)70 * HEVCE_TOKEN_SLOTS * HEVCE_FTOKEN_SLOT_WORDS   /* FAST slots have no header */
+                : (HV_GLOBAL u16 *)(s0 + HEVCE_SCR_XTOK) + (size_t)70 * HEVCE_TOKEN_SLOTS * HEVCE_TOKEN_SLOT_WORDS + HV_SLOT_TOK0;
+}
 
 static HD void hv_mpm(int left, int above, int out[3]) {                                                   /* [ref :958-977] */
     if (left != above) {
@@ -559,10 +568,10 @@ template <typename WR> static HD void hv_emit_b(WR &w, int bins, int len, int on
    and leave it as 16-byte chunks.  hv_tok_checkpoint() writes out up to three complete chunks; between two checkpoints
    at most 24 tokens may be added. */
 typedef unsigned __attribute__((may_alias)) HvRingWord;    /* written as 16-bit halves, read back as dwords */
-template <bool FAST> struct HvTokRingT { HV_LDSP HvRingWord *ring; HV_GLOBAL u16 *slot; int n, fl, byp; enum { fast = FAST }; };
-template <bool FAST> static HD HvTokRingT<FAST> hv_tok_ring(HvLds &S, HV_GLOBAL u16 *slot) {
+template <bool FAST> struct HvTokRingT { HV_LDSP HvRingWord *ring; HV_GLOBAL u16 *slot; int n, fl, byp, tok0; enum { fast = FAST }; };
+template <bool FAST> static HD HvTokRingT<FAST> hv_tok_ring(HvLds &S, HV_GLOBAL u16 *slot, int tok0 = HV_SLOT_TOK0) {
     const int tid = hv_tid();
-    HvTokRingT<FAST> w = { (HV_LDSP HvRingWord *)&S.ws[tid >> 6] + (tid & 63), slot, 0, 0, 0 };
+    HvTokRingT<FAST> w = { (HV_LDSP HvRingWord *)&S.ws[tid >> 6] + (tid & 63), slot, 0, 0, 0, tok0 };
     return w;
 }
 template <bool F> static HD void hv_emit(HvTokRingT<F> &w, int tok, int on) {
@@ -573,7 +582,7 @@ template <bool F> static HD void hv_tok_flush_chunk(HvTokRingT<F> &w) {
     const HV_LDSP HvRingWord *r = w.ring + ((w.fl >> 1) & 15) * 64;
     HvChunk c;
     c[0] = r[0]; c[1] = r[64]; c[2] = r[128]; c[3] = r[192];
-    *(HV_GLOBAL HvChunk *)(w.slot + HV_SLOT_TOK0 + w.fl) = c;
+    *(HV_GLOBAL HvChunk *)(w.slot + w.tok0 + w.fl) = c;
     w.fl += 8;
 }
 template <bool F> static HD void hv_tok_checkpoint(HvTokRingT<F> &w) {
@@ -585,6 +594,9 @@ template <bool F> static HD int hv_tok_finish(HvTokRingT<F> &w) {               
 #pragma unroll
     for (int i = 0; i < 7; i++) ((HV_LDSP u16 *)(w.ring + (((w.n + i) >> 1) & 15) * 64))[(w.n + i) & 1] = (u16)(F ? HV_TOK_NOPF : HV_TOK_NOP);
     hv_tok_flush_chunk(w);                                    /* the last chunk, padded with no-ops */
+#ifdef HEVCE_EMU
+    if (F && w.tok0 == 0 && w.n > HEVCE_FTOKEN_SLOT_WORDS - 1) { fprintf(stderr, "emu: FAST slot overflow (%d tokens)\n", w.n); abort(); }
+#endif
     return (w.n + 7) >> 3;                                    /* chunks */
 }
 
@@ -1031,7 +1043,7 @@ static HD int hv_fengine_slots(const HvLds &S, HvFCod &c, u8 *cx, const HV_GLOBA
                                int dead, int *shared, int notify, int q, int sse, int bitsbase, int *best) {
     int e = ls[hv_min(k, nlist - 1)];
     int nch = e >> 8;
-    const HV_GLOBAL HvChunk *ptr = (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HV_SLOT + HV_SLOT_TOK0) + ci;
+    const HV_GLOBAL HvChunk *ptr = (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HEVCE_FTOKEN_SLOT_WORDS) + ci;
     HvChunk nxt = *ptr;
     int it = 0, pub = 0;
     HvFA A; HvFB B;
@@ -1052,7 +1064,7 @@ static HD int hv_fengine_slots(const HvLds &S, HvFCod &c, u8 *cx, const HV_GLOBA
             e = ls[hv_min(k, nlist - 1)];
             ci = adv ? 0 : ci;
             nch = adv ? (e >> 8) : nch;
-            ptr = adv ? (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HV_SLOT + HV_SLOT_TOK0) : ptr + 1;
+            ptr = adv ? (const HV_GLOBAL HvChunk *)(slots + (e & 0xff) * HEVCE_FTOKEN_SLOT_WORDS) : ptr + 1;
             nxt = *ptr;
             hv_fengine_chunk(S, c, cx, cur, nxt, A, B);
             it++;
@@ -2137,7 +2149,7 @@ static HD void hv_bin_group(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL
         /* a 4x4 block is one group: its header (cbf_luma, last position) goes into the group's slot, in front of the group's
            tokens, and the header slot stays empty -- one padded slot less per block for the engines to walk (TU-split 8x8
            candidates: five slots instead of nine; they are the longest of an 8x8 CU's candidates) */
-        HvTokRingT<FAST> w4 = hv_tok_ring<FAST>(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * 2 + 1) * HV_SLOT);
+        HvTokRingT<FAST> w4 = hv_tok_ring<FAST>(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * 2 + 1) * HvSlotGeo<FAST>::words, HvSlotGeo<FAST>::tok0);
         hv_tokenize_tu_body<3>(S, w4, 4, 2, hv_scan_kind(4, t - 35), 1, CX_YCBF, cbf, L.tinfo[t][tu].last);
         sh = (u8)hv_cg_emit(S, w4, g, g1);
         hv_cnt(cn, t, 1 + tu * 2) = 0;
@@ -2145,7 +2157,7 @@ static HD void hv_bin_group(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GLOBAL
         return;
     }
     if (!cbf) { sh = 0; return; }
-    HvTokRingT<FAST> w = hv_tok_ring<FAST>(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt) + 1 + r) * HV_SLOT);
+    HvTokRingT<FAST> w = hv_tok_ring<FAST>(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt) + 1 + r) * HvSlotGeo<FAST>::words, HvSlotGeo<FAST>::tok0);
     sh = (u8)hv_cg_emit(S, w, g, g1);
     if (FAST) hv_atomic_add(&L.tnlog[t], w.byp);
 }
@@ -2154,7 +2166,7 @@ static HD void hv_bin_tu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GL
     const int kind = t < 35 ? 0 : (t < 70 ? 1 : 2);
     const int tn = kind == 0 ? cu.n : (cu.n >> 1), tlg = kind == 0 ? cu.lg : cu.lg - 1, ncgt = (tn >> 2) * (tn >> 2);
     const int md = kind == 0 ? t : kind == 1 ? t - 35 : S.nxn_modes[tu];
-    HvTokRingT<FAST> w = hv_tok_ring<FAST>(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt)) * HV_SLOT);
+    HvTokRingT<FAST> w = hv_tok_ring<FAST>(S, gtok + ((size_t)t * HV_SLOTS_TRIAL + 1 + tu * (1 + ncgt)) * HvSlotGeo<FAST>::words, HvSlotGeo<FAST>::tok0);
     hv_cnt(cn, t, 1 + tu * (1 + ncgt)) = (u8)hv_tokenize_tu(S, w, tn, tlg, hv_scan_kind(tn, md), 1, kind == 0 ? CX_YCBF + 1 : CX_YCBF,
                                                          L.tinfo[t][tu].cbf, L.tinfo[t][tu].last);
     if (FAST) hv_atomic_add(&L.tnlog[t], w.byp);
@@ -2174,7 +2186,7 @@ static HD void hv_bin_cu_header(HvLds &S, HvLds::Level &L, const HvCu &cu, HV_GL
         pm.left[2] = S.map_pm[my + 1][mx - 1];  pm.above[2] = pm.mode[0];
         pm.left[3] = pm.mode[2];  pm.above[3] = pm.mode[1];
     }
-    HvTokRingT<FAST> w = hv_tok_ring<FAST>(S, gtok + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT);
+    HvTokRingT<FAST> w = hv_tok_ring<FAST>(S, gtok + (size_t)t * HV_SLOTS_TRIAL * HvSlotGeo<FAST>::words, HvSlotGeo<FAST>::tok0);
     hv_cnt(cn, t, 0) = (u8)hv_tokenize_cu(w, cu.n, cu.lg, kind, L.split_inc, pm);
     if (FAST) hv_atomic_add(&L.tnlog[t], w.byp);
 }
@@ -2228,7 +2240,8 @@ static HDN void hv_run_engines(HV_GLOBAL u8 *scratch, int q, int mask, int *shar
             const int pos = L.tpos[t], nlist = L.tlen[t];
             int k = pos & 0xff, ci = pos >> 8;
             HV_GLOBAL u8 *lscr = scratch + (size_t)lvl * HEVCE_SCRATCH_LEVEL_BYTES;
-            const HV_GLOBAL u16 *slots = (const HV_GLOBAL u16 *)(lscr + HV_TL * 1024 * 3) + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT;
+            const HV_GLOBAL u16 *slots = fast ? (const HV_GLOBAL u16 *)(lscr + HEVCE_SCR_FTOK) + (size_t)t * HV_SLOTS_TRIAL * HEVCE_FTOKEN_SLOT_WORDS
+                                              : (const HV_GLOBAL u16 *)(lscr + HEVCE_SCR_XTOK) + (size_t)t * HV_SLOTS_TRIAL * HV_SLOT;
             int dead, cost;
             if (fast) {
                 HvFCod c = { L.tregs[t].range, L.tregs[t].nbits };
@@ -2242,7 +2255,7 @@ static HDN void hv_run_engines(HV_GLOBAL u8 *scratch, int q, int mask, int *shar
                 HvCod c;
                 hv_cod_load(c, L.tregs[t]);
                 const int bits0 = hv_regs_bits(S.ent[lvl]);
-                HV_GLOBAL u16 *sink = (HV_GLOBAL u16 *)(lscr + HV_TL * 1024 * 3 + (size_t)HV_TL * HV_SLOTS_TRIAL * HV_SLOT * 2) + (size_t)t * HEVCE_SINK_WORDS;
+                HV_GLOBAL u16 *sink = (HV_GLOBAL u16 *)(lscr + HEVCE_SCR_SINK) + (size_t)t * HEVCE_SINK_WORDS;
                 dead = hv_rdcost(q, L.tsse[t], hv_cod_bits(c) - bits0) > hv_peek(&L.best_cost);
                 hv_cod_span(c);
                 const int nlog = L.tnlog[t];                      /* EXACT: tnlog = byte records in the sink so far */
@@ -2284,7 +2297,7 @@ static HDN void hv_bin_own(HV_GLOBAL u8 *scr, HvCu cu, int tb, int tc) {
     const int lane = hv_tid() & 63;
     cu.lvl = hv_uni(cu.lvl); cu.n = hv_uni(cu.n); cu.lg = hv_uni(cu.lg); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x);
     HvLds::Level &L = S.lv[cu.lvl];
-    HV_GLOBAL u16 *gtok = (HV_GLOBAL u16 *)(scr + HV_TL * 1024 * 3);
+    HV_GLOBAL u16 *gtok = (HV_GLOBAL u16 *)(scr + HvSlotGeo<FAST>::base);
     const int ncg = (cu.n >> 2) * (cu.n >> 2), per = 64 / ncg;
     tb = hv_uni(tb); tc = hv_uni(tc);
     /* slot counts of these (<= 16) candidates: behind the token ring in this wavefront's scratch tile */
@@ -2406,7 +2419,7 @@ static HDN void hv_wr_tokenise(const HevceImageDesc &im, int cw) {
         const int g1 = before ? (int)((bg1 >> (63 - hv_clzll(before))) & 1) : 0;
         int ch = 0;
         if (cbf && cg <= cg_last) {
-            HvTokRingT<false> w = hv_tok_ring<false>(S, slots + (size_t)(2 * 64 + lane) * HV_SLOT);
+            HvTokRingT<false> w = hv_tok_ring<false>(S, slots + (size_t)(2 * 64 + lane) * HV_WSLOT);
             ch = hv_cg_emit(S, w, g, g1);
         }
         W.cnt[2][lane] = (u8)ch;
@@ -2415,7 +2428,7 @@ static HDN void hv_wr_tokenise(const HevceImageDesc &im, int cw) {
     {
         int ch = 0;
         if (lane == base) {
-            HvTokRingT<false> w = hv_tok_ring<false>(S, slots + (size_t)(64 + lane) * HV_SLOT);
+            HvTokRingT<false> w = hv_tok_ring<false>(S, slots + (size_t)(64 + lane) * HV_WSLOT);
             ch = hv_tokenize_tu(S, w, tn, tlg, kind, 1, (nxn || split) ? CX_YCBF : CX_YCBF + 1, cbf, last);
         }
         W.cnt[1][lane] = (u8)ch;
@@ -2425,7 +2438,7 @@ static HDN void hv_wr_tokenise(const HevceImageDesc &im, int cw) {
         int ch = 0;
         if (lane == cubase) {
             const int y = cy * 4, x = cx4 * 4;
-            HvTokRingT<false> w = hv_tok_ring<false>(S, slots + (size_t)lane * HV_SLOT);
+            HvTokRingT<false> w = hv_tok_ring<false>(S, slots + (size_t)lane * HV_WSLOT);
             const int inc32 = (32 > hv_wr_cu_left(S, L, 0, 0)) + (32 > hv_wr_cu_above(S, A, 0, 0));
             hv_emit(w, HV_CT(CX_SPLIT_CU + inc32, 1), lane == 0 && n < 32);
             const int inc16 = (16 > hv_wr_cu_left(S, L, y & ~15, x & ~15)) + (16 > hv_wr_cu_above(S, A, y & ~15, x & ~15));
@@ -2503,7 +2516,7 @@ static HDN void hv_wr_engine(const HevceImageDesc &im_, int cw, int budget) {
     int pos = hv_uni(T.pos), ci = hv_uni(T.ci);
     /* the chunk at (pos, ci), or the first one after it; pos = 192: none left */
     #define HV_WR_SEEK() do { while (pos < 192) { const int z_ = pos / 3, k_ = pos - 3 * z_; if (ci < hv_uni((int)W.cnt[k_][z_])) break; pos++; ci = 0; } } while (0)
-    #define HV_WR_ADDR() ((const HV_GLOBAL HvChunk *)(slots + (size_t)((pos - 3 * (pos / 3)) * 64 + pos / 3) * HV_SLOT + HV_SLOT_TOK0) + ci)
+    #define HV_WR_ADDR() ((const HV_GLOBAL HvChunk *)(slots + (size_t)((pos - 3 * (pos / 3)) * 64 + pos / 3) * HV_WSLOT + HV_SLOT_TOK0) + ci)
     HV_WR_SEEK();
     HvChunk nxt = { 0, 0, 0, 0 };
     if (pos < 192) nxt = *HV_WR_ADDR();
@@ -2600,7 +2613,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     if (wv == 0) {
         /* the NxN chain; it also writes the token stream, slot list and engine state of its outcome, candidate 70, and
            clears S.nxn_busy shortly before its end */
-        HV_GLOBAL u16 *c70 = (HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3) + (size_t)70 * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0;
+        HV_GLOBAL u16 *c70 = hv_c70_area(s0, fast);
         if (fast) hv_job_nxn<true>(wave, lane, q, c8, c70, hv_uni(cl) == 2);
         else hv_job_nxn<false>(wave, lane, q, c8, c70, 0);
         return;
@@ -2615,7 +2628,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         return;
     }
     if (hv_uni(cl) == 2) {                                       /* cluster of 4: this CU's block jobs and candidates 0..69 are another workgroup's */
-        if (wv == 5) hv_c70_rider((HV_GLOBAL u16 *)(s0 + HV_TL * 1024 * 3) + (size_t)70 * HV_SLOTS_TRIAL * HV_SLOT + HV_SLOT_TOK0, q);
+        if (wv == 5) hv_c70_rider(hv_c70_area(s0, 1), q);          /* FAST analysis only (cl == 2) */
         if (wv >= 1 && wv <= 3) hv_nxn_helper(q, c8, wv - 1);      /* the NxN chain's block trials, 16 modes each */
         if (wv == 6 && k16 == 0 && m == 0 && hv_uni(S.nxv_pend)) hv_verify_nxn(lane, 1);   /* the previous CTU's NxN winners, off the critical path */
         return;

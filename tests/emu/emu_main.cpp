@@ -140,6 +140,23 @@ int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, 
     }
     for (int i = 0; i < nfib; i++) free(fib[i].stack);
     for (int g = 0; g < nwg; g++) free(g_lds[g]);
+    if (getenv("HEVCE_EMU_FOOTPRINT")) {                   /* 128-byte lines of the trial scratch the picture touched, per CU level and region */
+        const size_t reg[5] = { 0, HEVCE_SCR_FTOK, HEVCE_SCR_XTOK, HEVCE_SCR_SINK, HEVCE_SCRATCH_LEVEL_BYTES };
+        size_t all = 0;
+        for (int l = 0; l < 3; l++) for (int r = 0; r < 4; r++) {
+            size_t n = 0;
+            for (size_t a = l * (size_t)HEVCE_SCRATCH_LEVEL_BYTES + reg[r]; a < l * (size_t)HEVCE_SCRATCH_LEVEL_BYTES + reg[r + 1]; a += 128) {
+                bool hit = false;
+                for (int b = 0; b < 128 && !hit; b++) hit = scratch[a + b] != 0xCD;
+                n += hit;
+            }
+            fprintf(stderr, "footprint level %d %s: %zu lines = %zu KB\n", l, r == 0 ? "levels+samples" : r == 1 ? "FAST tokens" : r == 2 ? "EXACT tokens" : "sinks", n, n / 8);
+            all += n;
+        }
+        size_t w = 0;
+        for (size_t a = 0; a < HEVCE_WRTOK_BYTES; a += 128) { bool hit = false; for (int b = 0; b < 128 && !hit; b++) hit = wrtok[a + b] != 0xEF; w += hit; }
+        fprintf(stderr, "footprint writer tokens: %zu lines; trial scratch in all: %zu KB\n", w, all / 8);
+    }
     if (cluster > 1 && cl.error) rc = -2;
     return rc;
 }
