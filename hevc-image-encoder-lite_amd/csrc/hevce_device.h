@@ -81,6 +81,7 @@ static HD void hv_atomic_dec(int *p) { atomicSub(p, 1); }
 static HD void hv_flag_clear(int *p) { __hip_atomic_store(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 static HD void hv_flag_set(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define HV_FENCE_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#define HV_FENCE_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
 static HD int  hv_mul24(int a, int b) { return __mul24(a, b); }
 static HD unsigned hv_umul24(unsigned a, unsigned b) { return __umul24(a, b); }   /* both < 2^24: low 32 bits of the product, full rate */
 static HD int  hv_clz(unsigned v) { return __clz((int)v); }          /* 32 for v == 0 */
@@ -139,16 +140,15 @@ static HD unsigned hv_ldg_u32(const unsigned *p) { return __hip_atomic_load(p, _
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
 #define HV_PROF_T0()  unsigned long long pt_ = __builtin_amdgcn_s_memtime()
 #define HV_PROF2_T0() unsigned long long p2_ = __builtin_amdgcn_s_memtime()
-#define HV_PROF3(S, ph) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof2[ph] += n_ - pt_; pt_ = n_; } } while (0)
-#define HV_PROF3L(k) HV_PROF3(S, 4 + 4 * cu.lvl + (k))
+/* chain workgroup, cluster of four: the section between two 8x8 jobs phases, piece i into prof2[5 + i] (i < 0: only restart the clock) */
+#define HV_PROFC(S, i) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if ((i) >= 0) (S).prof2[5 + (i)] += n_ - (S).prof_pt; (S).prof_pt = n_; } } while (0)
 #define HV_PROF2(S, ph) do { if ((hv_tid() & 63) == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof2[ph] += n_ - p2_; p2_ = n_; } } while (0)
 #define HV_PROF(S, lvl, ph) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof[lvl][ph] += n_ - pt_; pt_ = n_; } } while (0)
 #else
 #define HV_PROF_T0() do { } while (0)
 #define HV_PROF2_T0() do { } while (0)
 #define HV_PROF2(S, ph) do { } while (0)
-#define HV_PROF3(S, ph) do { } while (0)
-#define HV_PROF3L(k) do { } while (0)
+#define HV_PROFC(S, i) do { } while (0)
 #define HV_PROF(S, lvl, ph) do { } while (0)
 #endif
 
@@ -303,6 +303,7 @@ struct alignas(16) HvLds {
     } wst;
 #ifdef HEVCE_ANYPROF
     unsigned long long prof[3][8];
+    unsigned long long prof_pt;                              /* HEVCE_PROF: running stamp of the chain workgroup's hand-off section (HV_PROFC) */
     unsigned long long prof2[32];                           /* HEVCE_PROF: inside the NxN job (tu jobs, tokenise, engine, select) */
 #endif
     int *trace;
@@ -596,6 +597,7 @@ template <bool F> static HD int hv_tok_finish(HvTokRingT<F> &w) {               
     hv_tok_flush_chunk(w);                                    /* the last chunk, padded with no-ops */
 #ifdef HEVCE_EMU
     if (F && w.tok0 == 0 && w.n > HEVCE_FTOKEN_SLOT_WORDS - 1) { fprintf(stderr, "emu: FAST slot overflow (%d tokens)\n", w.n); abort(); }
+    if (F && w.tok0 == 0) { emu_tok_stat[0] += w.n; emu_tok_stat[1] += (w.n + 7) >> 3; emu_tok_stat[2] += 1; }
 #endif
     return (w.n + 7) >> 3;                                    /* chunks */
 }
@@ -2618,9 +2620,11 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         else hv_job_nxn<false>(wave, lane, q, c8, c70, 0);
         return;
     }
-    if (wv == 4) {
-        /* shares its SIMD with wavefront 0, so no jobs: one of its lanes writes the previous CTU's slice data instead (slice = this
-           round's 8x8 position); the older wavefront 0 wins the SIMD's issue arbitration */
+    if (wv == (hv_uni(cl) == 2 ? 7 : 4)) {
+        /* wavefront 4 shares its SIMD with wavefront 0, so no jobs: it writes the previous CTU's slice data instead (slice = this
+           round's 8x8 position); the older wavefront 0 wins the SIMD's issue arbitration.  Cluster of four: wavefronts are to spare,
+           the writer is wavefront 7 (measured: on wavefront 4 its slice, 91 k cycles, outlasted the NxN chain's 79 k and took issue
+           slots from it), wavefront 4 idles and the NxN chain has its SIMD to itself; the tile in ws[4] stays the writer's */
         if (wr_on) {
             if (k16 == 0 && m == 0) { hv_wr_stage(S, im, ctu - 1); WAVE_SYNC(); hv_wr_tokenise(im, ctu - 1); WAVE_SYNC(); }
             hv_wr_engine(im, ctu - 1, (k16 * 4 + m) == 15 ? 100000 : S.wst.budget);
@@ -2692,7 +2696,7 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
     const int ntrials = (n == 8) ? 71 : 70;
     const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
     HV_PROF_T0();
-    if (n == 8 && cl == 2) hv_cl_receive(S, im, cu);            /* cluster of 4: candidates 0..69 were evaluated elsewhere, the best of them joins candidate 70 */
+    if (n == 8 && cl == 2) { HV_PROFC(S, -1); hv_cl_receive(S, im, cu); HV_PROFC(S, 1); }   /* cluster of 4: candidates 0..69 were evaluated elsewhere, the best of them joins candidate 70 */
     if (n > 8) {
         /* the split alternative is the state the children left behind  [ref :1409-1410]; it also bounds the pruning */
         if (hv_uni(wave) == 0) hv_job_sse(S, lane, cu);
@@ -2735,6 +2739,7 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
     BLOCK_SYNC();
     const int w = S.winner;
     HV_PROF(S, cu.lvl, 3);
+    if (n == 8 && cl == 2) HV_PROFC(S, 2);
     if (w < 0) return;                                          /* the four sub-CUs stay */
 
     /* ---------------- commit the winner: coder, contexts, reconstruction, maps, record ---------------- */
@@ -2769,6 +2774,7 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
     }
     BLOCK_SYNC();
     HV_PROF(S, cu.lvl, 4);
+    if (n == 8 && cl == 2) HV_PROFC(S, 3);
 }
 
 /* --------------------------------------------------------------------------------------------- */
@@ -2933,6 +2939,7 @@ static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu) 
         const unsigned long long to = (im.flags & 4) ? 100000ull : HV_CL_TIMEOUT;   /* test hook (flag bit 2): the workers have left, give up after 1 ms */
         if (!hv_cl_wait(&im.cluster->res[b].seq, S.cl_seq[b], &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
         if (two && !hv_cl_wait(&im.cluster->res[3].seq, S.cl_seq[b], &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
+        if (cu.lvl == 0) HV_PROFC(S, 0);                         /* waited for the 8x8 answer */
     }
     BLOCK_SYNC();
     const HevceRes *r = &im.cluster->res[b], *r2 = &im.cluster->res[two ? 3 : b];
@@ -2980,16 +2987,26 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
             /* 3 chains (16 modes each, candidates 35..69) + 5 single blocks (8 modes each, candidates 0..34): one job per wavefront,
                and everything that follows for the candidates of that job -- binarisation, engines -- in the same wavefront: nothing
                depends on another wavefront until the arg-min, so there is no barrier in between (the 8x8 answer is on the chain
-               workgroup's critical path) */
+               workgroup's critical path).  Gathering all engines on two wavefronts (35 lanes each) changes nothing: a wavefront's
+               engine loop is bound by its own chain of LDS look-ups, not by the SIMD it shares (experiments/README.md) */
             hv_level_contexts(S, im, cu);                        /* ends with a barrier */
             const int nchain = hi > 35 ? 3 : 0;
             int tb = -1, tc = 0;
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+            unsigned long long w8_ = __builtin_amdgcn_s_memtime();
+#define HV_W8T(i) do { if (lane == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[8 + 3 * wv + (i)] += n_ - w8_; w8_ = n_; } } while (0)
+#else
+#define HV_W8T(i) do { } while (0)
+#endif
             if (wv < nchain) { hv_job_chain<4>(wave, lane, q, cu, wv, glev, grec); tb = 35 + 16 * wv; tc = hv_min(16, 70 - tb); }
             else if (lo < 35 && wv - nchain < 5) { hv_job_single<8>(wave, lane, q, cu, wv - nchain, glev, grec); tb = 8 * (wv - nchain); tc = hv_min(8, 35 - tb); }
+            HV_W8T(0);
             if (tb >= 0) {
                 hv_bin_own<true>(scr, cu, tb, tc);
                 WAVE_SYNC();
+                HV_W8T(1);
                 hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, 1, nullptr, -tc, tb);
+                HV_W8T(2);
             }
         } else if (cu.n == 16) {
             /* 5 chains (8 modes each) + 9 single blocks (4 modes each) over 8 wavefronts */
@@ -3134,7 +3151,7 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
         }
     }
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
-    if (im.trace && (serve & 4) && slot8 == 2 && tid < 8) ((unsigned long long *)im.trace)[80 + tid] = S.prof2[tid];   /* 8x8 worker: wait, accept, stages 0..2, messages */
+    if (im.trace && (serve & 4) && slot8 == 2 && tid < 32) ((unsigned long long *)im.trace)[80 + tid] = S.prof2[tid];   /* 8x8 worker: wait, accept, stages 0..2, messages */
 #endif
 }
 
@@ -3270,7 +3287,9 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                         /* the candidates of this CU other than the NxN one are another workgroup's: only candidate 70 runs here */
                         if (tid < 70) { S.lv[0].tdead[tid] = 1; S.lv[0].tpos[tid] = -1; }
                         if (tid == 0) S.l0_active = 1;
+                        HV_PROFC(S, 5);                          /* since the last 8x8 decision: enclosing CUs' decisions and entries, snapshot, level begin */
                         hv_cl_send(S, im, cu, ctu, 1);
+                        HV_PROFC(S, 6);
                     }
                     HV_PROF_T0();
 #ifdef HEVCE_PROF_JDUR
@@ -3296,6 +3315,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                 }
                 hv_decide_cu(S, im, cu, ctu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr, cl + cl8);
                 if (cl && (cu.n == 16 || (cl8 && cu.n == 8))) hv_cl_store_rcon(S, im, cu, y0, x0);   /* the next CU's candidates elsewhere predict from these samples */
+                if (cl8 && cu.n == 8) HV_PROFC(S, 4);
             }
 
         }

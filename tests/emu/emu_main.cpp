@@ -67,6 +67,7 @@ void emu_block_sync(void) {
     yield_to_sched();
 }
 
+long long emu_tok_stat[4];
 extern "C" __attribute__((visibility("default")))
 int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, uint8_t *records, int32_t *ctu_state, int32_t *dump,
                 uint8_t *payload, int32_t *payload_len, int flags, int32_t *stats, int cluster) {
@@ -140,6 +141,8 @@ int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, 
     }
     for (int i = 0; i < nfib; i++) free(fib[i].stack);
     for (int g = 0; g < nwg; g++) free(g_lds[g]);
+    if (getenv("HEVCE_EMU_FOOTPRINT")) fprintf(stderr, "FAST trial slots: %lld tokens in %lld chunks of 8 in %lld slots (%.1f tokens, %.2f chunks per slot; fill %.0f %%)\n", emu_tok_stat[0], emu_tok_stat[1], emu_tok_stat[2],
+        (double)emu_tok_stat[0] / emu_tok_stat[2], (double)emu_tok_stat[1] / emu_tok_stat[2], 12.5 * emu_tok_stat[0] / emu_tok_stat[1]);
     if (getenv("HEVCE_EMU_FOOTPRINT")) {                   /* 128-byte lines of the trial scratch the picture touched, per CU level and region */
         const size_t reg[5] = { 0, HEVCE_SCR_FTOK, HEVCE_SCR_XTOK, HEVCE_SCR_SINK, HEVCE_SCRATCH_LEVEL_BYTES };
         size_t all = 0;

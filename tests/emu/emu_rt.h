@@ -6,6 +6,7 @@
  * product library; the product has no CPU path.
  */
 #pragma once
+extern long long emu_tok_stat[4];   /* FAST trial slots: tokens, chunks, slots (diagnostics) */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -59,6 +60,7 @@ static inline void hv_atomic_dec(int *p) { (*p)--; }
 static inline void hv_flag_clear(int *p) { *p = 0; }
 static inline void hv_flag_set(int *p, int v) { *p = v; }
 #define HV_FENCE_RELEASE() do { } while (0)
+#define HV_FENCE_ACQUIRE() do { } while (0)
 static inline int hv_mul24(int a, int b) {
     if (a < -(1 << 23) || a >= (1 << 23) || b < -(1 << 23) || b >= (1 << 23)) { fprintf(stderr, "emu: mul24 operand out of range %d %d\n", a, b); abort(); }
     return a * b;

@@ -40,6 +40,13 @@ if kind == "phases":
     wk = tr[160:176].view(np.uint64).astype(float)
     if wk[5] > 0:
         print("  8x8 worker (cluster >= 4), k cycles per message: wait %.1f, accept %.1f, jobs %.1f, contexts+binarise %.1f, engines+answer %.1f" % tuple(wk[i] / wk[5] / 1e3 for i in range(5)))
+        pw = tr[160:224].view(np.uint64).astype(float)[8:32].reshape(8, 3) / wk[5] / 1e3
+        for wv in range(8):
+            print("    wavefront %d (%s): block jobs %.1f, binarise %.1f, engines %.1f" % (wv, "TU-split chains, 16 modes" if wv < 3 else "single blocks, 8 modes", pw[wv, 0], pw[wv, 1], pw[wv, 2]))
+    if wk[5] > 0:
+        hs = p2[5:12] / nctu / 16 / 1e3
+        print("  chain workgroup between two 8x8 jobs phases, k cycles per round: wait for the answer %.1f, take it over %.1f, arg-min %.1f, commit %.1f, "
+              "samples to HBM %.1f, up to the next CU's message %.1f, send %.1f" % tuple(hs))
     print("  NxN chain:", "  ".join(f"{nm} {100.0*p2[i]/tot:5.1f}%" for i, nm in enumerate(("4x4 pipelines", "tokenise", "engine", "select", "tail"))))
 elif kind == "nxn":
     stages = nctu * 64
@@ -59,6 +66,10 @@ elif kind == "bin":
     for lvl, (nm, calls) in enumerate((("8x8  (16 calls, 16 candidates)", 16), ("16x16 (4 calls, 12 candidates)", 4), ("32x32 (1 call, 12 candidates)", 1))):
         v = p2[16 + 4 * lvl:20 + 4 * lvl] / nctu / calls / 1e3
         print(f"{nm:32s} k cycles per call: groups {v[0]:7.1f}  TU headers {v[1]:6.1f}  CU headers {v[2]:6.1f}  slot lists {v[3]:6.1f}")
+    wk = tr[160:224].view(np.uint64).astype(float)
+    if wk[5] > 0:
+        v = wk[16:20] / wk[5] / 1e3
+        print(f"8x8 worker, wavefront 1 (16 TU-split candidates), k cycles per message: groups {v[0]:.1f}  TU headers {v[1]:.1f}  CU headers {v[2]:.1f}  slot lists {v[3]:.1f}")
 elif kind == "tu":
     N = int(arg)
     v6 = p2[16:22]
