@@ -62,6 +62,12 @@ typedef struct HevceMsg {      /* analysis workgroup -> parent workgroup: "evalu
     int32_t L, LB, A, AR;      /* neighbour availability */
     int32_t pad_;
     uint8_t ctx[104];          /* contexts at the CU's entry */
+    /* 8x8 mailbox: the message opens a 16x16 quad.  The 8x8 workgroup walks its four CUs on its own (it learns each decision from
+       its own answer and the chain's HevceNxn report), so it also needs the quad's availability and the modes beside its lower /
+       right halves (ml, ma above are those beside CU 0)  [ref HEVCe.c:1369-1373] */
+    int32_t ml2, ma2;          /* mode left of the quad's row 8, above its column 8 */
+    int32_t qL, qLB, qA, qAR;  /* the 16x16 CU's neighbour availability */
+    int32_t pad2_[2];
 } HevceMsg;
 typedef struct HevceRes {      /* parent workgroup -> analysis workgroup: the best unsplit candidate */
     int32_t seq;               /* = the message it answers, written last (release) */
@@ -70,7 +76,19 @@ typedef struct HevceRes {      /* parent workgroup -> analysis workgroup: the be
     int32_t pad_[2];
     uint8_t ctx[104];          /* contexts after it */
 } HevceRes;
-typedef struct HevceCluster { HevceMsg msg[3]; HevceRes res[4]; int32_t error; int32_t size; int32_t pad_[2]; } HevceCluster;   /* mailboxes: 16x16, 32x32, 8x8 (4 / 5 workgroups); res[3]: the second 8x8 workgroup's answer (5) */
+typedef struct HevceNxn {      /* analysis workgroup -> 8x8 workgroup, once per 8x8 CU: the CU's NxN candidate (number 70), which only the chain knows */
+    int32_t seq;               /* number of the 8x8 CU since the launch, written last (release) */
+    int32_t cost;
+    int32_t range, nbits;      /* coder after it (nbits with its bypass bins taken off) */
+    int32_t modes;             /* its four luma modes, 8 bits each, block 0 lowest */
+    int32_t pad_[3];
+    uint8_t ctx[104];          /* contexts after it */
+    uint8_t rec[64];           /* its reconstruction, 8 x 8 */
+} HevceNxn;
+/* mailboxes: msg / res 0: 16x16, 1: 32x32, msg 2: 8x8 (clusters of four: one message per 16x16 quad); the 8x8 answers alternate between
+   res[2] and res[3] and the NxN reports between nxn[0] and nxn[1] (by the parity of the CU's number), so that neither side can
+   overwrite what the other is still reading */
+typedef struct HevceCluster { HevceMsg msg[3]; HevceRes res[4]; HevceNxn nxn[2]; int32_t error; int32_t size; int32_t pad_[2]; } HevceCluster;
 
 /* one image of a batch, as the kernel sees it (all pointers are device pointers) */
 typedef struct HevceImageDesc {
@@ -108,5 +126,7 @@ typedef struct HevceImageDesc {
 #define HEVCE_SCR_XTOK   (HEVCE_SCR_FTOK + HEVCE_TRIALS * HEVCE_TOKEN_SLOTS * HEVCE_FTOKEN_SLOT_WORDS * 2)
 #define HEVCE_SCR_SINK   (HEVCE_SCR_XTOK + HEVCE_TRIALS * HEVCE_TOKEN_SLOTS * HEVCE_TOKEN_SLOT_WORDS * 2)
 #define HEVCE_SCRATCH_LEVEL_BYTES (HEVCE_SCR_SINK + HEVCE_TRIALS * HEVCE_SINK_WORDS * 2)
-#define HEVCE_SCRATCH_BYTES (3 * HEVCE_SCRATCH_LEVEL_BYTES)   /* one set per CU level: 8x8, 16x16, 32x32 candidates coexist */
+#define HEVCE_SCRATCH_BYTES (4 * HEVCE_SCRATCH_LEVEL_BYTES)   /* one set per CU level: 8x8, 16x16, 32x32 candidates coexist; the fourth: the 8x8 workgroup of a
+                                                                cluster alternates between sets 0 and 3 (the chain workgroup still reads the winner of CU k
+                                                                while the candidates of CU k + 1 are written) */
                                                              /* int16 levels + u8 reconstruction + bin tokens per trial */

@@ -279,7 +279,9 @@ struct alignas(16) HvLds {
     int   c70_done, c70_seg[4], c70_pat;                    /* FAST: stages whose winner's tokens are in the stream (5: header known too); per stage offset | tokens << 16 | cbf << 31; the CU header's four prev_intra_luma_pred_flags */
     u8    nxn_ctx[HEVCE_NCTXP][HV_TL];                      /* context columns of the NxN chain's 35 modes (fresh per 4x4 block) */
     /* control */
-    int cl_seq[3];                                          /* cluster mode: messages sent (chain workgroup) / answered (parent workgroup) per mailbox */
+    int cl_seq[3];                                          /* cluster mode: messages sent (chain workgroup) / answered (parent workgroup) per mailbox; 8x8 worker: quads accepted */
+    int cl_ans8;                                            /* 8x8 CUs reported (chain workgroup) / answered (8x8 workgroup) since the launch */
+    struct Quad8 { int ctu; u8 y, x, L, LB, A, AR, ml0, ml2, ma0, ma2, pad_[2]; u8 pm[4][4]; } q8;   /* 8x8 workgroup: the quad it is walking */
     int cl_pick, cl_fail;                                   /* parent workgroup: the mailbox to serve next (-1 exit); a hand-off timed out */
     int cl_light, cl_ok;                                    /* all partners share this workgroup's XCD (light hand-offs, see hv_publish_fence); chain workgroup: answer slots whose sender said so */
     int exact;                                              /* 1: EXACT engines (the reference's bit counts by construction); 0: FAST (see hv_fengine_chunk) */
@@ -2097,6 +2099,8 @@ static HDN void hv_verify_nxn(int lane, int deferred) {
 /*   hv_decide_cu   : split alternative, arg-min (last of minimum), commit                              */
 /* --------------------------------------------------------------------------------------------- */
 static HD HV_GLOBAL u8 *hv_level_scratch(const HevceImageDesc &im, int lvl) { return (HV_GLOBAL u8 *)(im.scratch + (size_t)lvl * HEVCE_SCRATCH_LEVEL_BYTES); }
+/* cluster of four: the 8x8 workgroup's candidates 0..69 of 8x8 CU number k (counted from the launch) live in set 0 or 3 by k's parity */
+static HD HV_GLOBAL u8 *hv_worker8_scratch(const HevceImageDesc &im, int k) { return (HV_GLOBAL u8 *)(im.scratch + ((k & 1) ? (size_t)3 * HEVCE_SCRATCH_LEVEL_BYTES : 0)); }
 static HD int hv_trial_slots(int n, int t) { const int tn = t < 35 ? n : (n >> 1); return 1 + (t < 35 ? 1 : 4) * (1 + (tn >> 2) * (tn >> 2)); }
 
 /* a CU is entered: neighbour context  [ref :1369-1373] and empty candidate state.  Needs a barrier before use. */
@@ -2690,7 +2694,7 @@ static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu);
 static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, HevceRecord *rec, int32_t *dump, int cl) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, n = cu.n;
     HvLds::Level &L = S.lv[cu.lvl];
-    HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
+    HV_GLOBAL u8 *scr = (n == 8 && cl == 2) ? hv_worker8_scratch(im, hv_uni(S.cl_ans8)) : hv_level_scratch(im, cu.lvl);   /* cl_ans8: this CU's number (hv_cl_send_nxn) */
     HvGLev glev = (HvGLev)scr;
     HvGRec grec = (HvGRec)(scr + HV_TL * 1024 * 2);
     const int ntrials = (n == 8) ? 71 : 70;
@@ -2914,7 +2918,7 @@ static HD int hv_cl_wait(const int *seq, int want, int *fail, int light, unsigne
 }
 /* chain workgroup: the CU of level lvl is entered (S.ent / S.ent_ctx / S.lv[lvl] hold its entry state): tell the parent workgroup.
    All threads; what the parents read of the picture's reconstruction has been stored by now (fence below). */
-static HD void hv_cl_send(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, int kind) {
+static HD void hv_cl_send(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, int kind, const HvCu *quad = nullptr) {   /* quad: the 16x16 CU an 8x8 message opens */
     const int tid = hv_tid(), b = HV_CL_BOX(cu.lvl);
     HevceMsg *m = &im.cluster->msg[b];
     const HvLds::Level &L = S.lv[cu.lvl];
@@ -2923,6 +2927,11 @@ static HD void hv_cl_send(HvLds &S, const HevceImageDesc &im, const HvCu cu, int
         m->range = S.ent[cu.lvl].range; m->nbits = S.ent[cu.lvl].nbits;
         m->split_inc = L.split_inc; m->ml = L.ml; m->ma = L.ma;
         m->L = cu.L; m->LB = cu.LB; m->A = cu.A; m->AR = cu.AR;
+        if (quad) {
+            const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
+            m->ml2 = S.map_pm[my + 2][mx - 1]; m->ma2 = S.map_pm[my - 1][mx + 2];
+            m->qL = quad->L; m->qLB = quad->LB; m->qA = quad->A; m->qAR = quad->AR;
+        }
     }
     if (tid < HEVCE_NCTXP) m->ctx[tid] = S.ent_ctx[cu.lvl][tid];
     if (tid == 0) m->pad_ = hv_xcc_id();                           /* where this workgroup sits: the receiver may take the light path if it sits there too */
@@ -2930,41 +2939,51 @@ static HD void hv_cl_send(HvLds &S, const HevceImageDesc &im, const HvCu cu, int
     BLOCK_SYNC();
     if (tid == 0) { const int s = S.cl_seq[b] + 1; S.cl_seq[b] = s; hv_st_flag(&m->seq, s); }
 }
+/* chain workgroup, cluster of four, after an 8x8 CU's jobs phase: the NxN candidate is complete (its rider has coded it) -- report it
+   to the 8x8 workgroup, which then knows the CU's decision as soon as it has its own best candidate and goes on to the quad's next
+   CU without waiting for this workgroup's commit.  All threads. */
+static HD void hv_cl_send_nxn(HvLds &S, const HevceImageDesc &im) {
+    const int tid = hv_tid(), k = S.cl_ans8 + 1;
+    HevceNxn *r = &im.cluster->nxn[k & 1];
+    const HvLds::Level &L = S.lv[0];
+    if (tid == 0) {
+        r->cost = L.tdead[70] ? HV_I32MAX : L.tcost[70]; r->range = L.tregs[70].range; r->nbits = L.tregs[70].nbits - L.tnlog[70];
+        r->modes = S.nxn_modes[0] | (S.nxn_modes[1] << 8) | (S.nxn_modes[2] << 16) | (S.nxn_modes[3] << 24);
+    }
+    if (tid < HEVCE_NCTXP) r->ctx[tid] = L.tctx[tid][70];
+    if (tid >= 128 && tid < 192) r->rec[tid - 128] = S.nxn_crec[(tid - 128) >> 3][(tid - 128) & 7];
+    hv_publish_fence(S.cl_light);
+    BLOCK_SYNC();
+    if (tid == 0) { S.cl_ans8 = k; hv_st_flag(&r->seq, k); }
+}
 /* chain workgroup, at the CU's decision: wait for the answer and make its candidate the only one alive of the level.  All threads. */
 static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu) {
     const int tid = hv_tid(), b = HV_CL_BOX(cu.lvl);
     HvLds::Level &L = S.lv[cu.lvl];
-    const int size = im.cluster->size, two = cu.lvl == 0 && size >= 5;   /* clusters of five: candidates 0..34 and 35..69 of an 8x8 CU come from a workgroup each */
+    const int size = im.cluster->size;
+    /* the answer to 8x8 CU number k (hv_cl_send_nxn counted it) is in res[2 + (k & 1)] */
+    const int want = cu.lvl == 0 ? hv_uni(S.cl_ans8) : hv_uni(S.cl_seq[b]), slot = cu.lvl == 0 ? 2 + (want & 1) : b;
     if (tid == 0) {
         const unsigned long long to = (im.flags & 4) ? 100000ull : HV_CL_TIMEOUT;   /* test hook (flag bit 2): the workers have left, give up after 1 ms */
-        if (!hv_cl_wait(&im.cluster->res[b].seq, S.cl_seq[b], &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
-        if (two && !hv_cl_wait(&im.cluster->res[3].seq, S.cl_seq[b], &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
+        if (!hv_cl_wait(&im.cluster->res[slot].seq, want, &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
         if (cu.lvl == 0) HV_PROFC(S, 0);                         /* waited for the 8x8 answer */
     }
     BLOCK_SYNC();
-    const HevceRes *r = &im.cluster->res[b], *r2 = &im.cluster->res[two ? 3 : b];
-    const int w = hv_min(hv_max(hv_ldc_i32(&r->winner), 0), 69), w2 = hv_min(hv_max(hv_ldc_i32(&r2->winner), 0), 69);
-    if (tid < HV_TL) L.tdead[tid] = tid != w && tid != w2 && !(cu.lvl == 0 && tid == 70);   /* 8x8: the NxN candidate is the chain workgroup's own */
+    const HevceRes *r = &im.cluster->res[slot];
+    const int w = hv_min(hv_max(hv_ldc_i32(&r->winner), 0), 69);
+    if (tid < HV_TL) L.tdead[tid] = tid != w && !(cu.lvl == 0 && tid == 70);   /* 8x8: the NxN candidate is the chain workgroup's own */
     if (tid == 0) {
         L.tcost[w] = hv_ldc_i32(&r->cost); L.tsse[w] = hv_ldc_i32(&r->sse); L.tregs[w] = S.ent[cu.lvl];
         L.tregs[w].range = hv_ldc_i32(&r->range); L.tregs[w].nbits = hv_ldc_i32(&r->nbits); L.tnlog[w] = 0; L.tpos[w] = -1;
         /* the senders say whether they share this workgroup's XCD; when all of the cluster's do, hand-offs go the light way */
-        int ok = S.cl_ok | (hv_ldc_i32(&r->pad_[0]) == 1 ? 1 << b : 0) | ((two && hv_ldc_i32(&r2->pad_[0]) == 1) ? 8 : 0);
+        int ok = S.cl_ok | (hv_ldc_i32(&r->pad_[0]) == 1 ? 1 << b : 0);
         S.cl_ok = ok;
-        const int need = size == 2 ? 3 : size == 3 ? 3 : size == 4 ? 7 : 15;
+        const int need = size <= 3 ? 3 : 7;
         if ((ok & need) == need) S.cl_light = 1;
     }
     if (tid < HEVCE_NCTXP) L.tctx[tid][w] = (u8)hv_ldc_u8(&r->ctx[tid]);
-    if (two) {
-        if (tid == 64) {
-            L.tcost[w2] = hv_ldc_i32(&r2->cost); L.tsse[w2] = hv_ldc_i32(&r2->sse); L.tregs[w2] = S.ent[cu.lvl];
-            L.tregs[w2].range = hv_ldc_i32(&r2->range); L.tregs[w2].nbits = hv_ldc_i32(&r2->nbits); L.tnlog[w2] = 0; L.tpos[w2] = -1;
-        }
-        if (tid >= 128 && tid < 128 + HEVCE_NCTXP) L.tctx[tid - 128][w2] = (u8)hv_ldc_u8(&r2->ctx[tid - 128]);
-    }
     BLOCK_SYNC();
 }
-/* the samples of a CU that has just been decided go to the picture's reconstruction at once (the parents of the NEXT CUs read them there) */
 static HD void hv_cl_store_rcon(HvLds &S, const HevceImageDesc &im, const HvCu cu, int y0, int x0) {
     for (int p = hv_tid(); p < cu.n * cu.n; p += HV_NTHREADS) {
         const int yy = cu.y + p / cu.n, xx = cu.x + p % cu.n;
@@ -2977,7 +2996,7 @@ static HD void hv_cl_store_rcon(HvLds &S, const HevceImageDesc &im, const HvCu c
 static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, int stage, int lo, int hi, int slot) {   /* candidates [lo, hi), answer to res[slot] */
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, wv = hv_uni(wave);
     HvLds::Level &L = S.lv[cu.lvl];
-    HV_GLOBAL u8 *scr = hv_level_scratch(im, cu.lvl);
+    HV_GLOBAL u8 *scr = cu.lvl == 0 ? hv_worker8_scratch(im, hv_uni(S.cl_ans8) + 1) : hv_level_scratch(im, cu.lvl);   /* 8x8: the CU being answered is number cl_ans8 + 1 */
     HvGLev glev = (HvGLev)scr;
     HvGRec grec = (HvGRec)(scr + HV_TL * 1024 * 2);
     if (stage == 0) {
@@ -3005,7 +3024,7 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
                 hv_bin_own<true>(scr, cu, tb, tc);
                 WAVE_SYNC();
                 HV_W8T(1);
-                hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, 1, nullptr, -tc, tb);
+                hv_run_engines(scr, q, 1, nullptr, -tc, tb);    /* level 0 of the set at scr */
                 HV_W8T(2);
             }
         } else if (cu.n == 16) {
@@ -3048,12 +3067,16 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
         }
         BLOCK_SYNC();
         const int w = hv_min(hv_max(S.winner, 0), 69);
-        HevceRes *r = &im.cluster->res[slot];
+        const int k8 = hv_uni(S.cl_ans8) + 1;                     /* 8x8: this is the answer to CU number k8 of the launch */
+        HevceRes *r = &im.cluster->res[cu.lvl == 0 ? 2 + (k8 & 1) : slot];
         if (tid == 0) { r->cost = L.tcost[w]; r->winner = w; r->sse = L.tsse[w]; r->range = L.tregs[w].range; r->nbits = L.tregs[w].nbits - L.tnlog[w]; r->pad_[0] = S.cl_light ? 1 : 2; }
         if (tid < HEVCE_NCTXP) r->ctx[tid] = L.tctx[tid][w];
         hv_publish_fence(S.cl_light);                            /* the answer, and the winner's levels / samples in the level scratch */
         BLOCK_SYNC();
-        if (tid == 0) { const int sq = S.cl_seq[HV_CL_BOX(cu.lvl)] + 1; S.cl_seq[HV_CL_BOX(cu.lvl)] = sq; hv_st_flag(&r->seq, sq); }
+        if (tid == 0) {
+            if (cu.lvl == 0) { S.cl_ans8 = k8; hv_st_flag(&r->seq, k8); }
+            else { const int sq = S.cl_seq[HV_CL_BOX(cu.lvl)] + 1; S.cl_seq[HV_CL_BOX(cu.lvl)] = sq; hv_st_flag(&r->seq, sq); }
+        }
     }
     BLOCK_SYNC();
 }
@@ -3070,6 +3093,11 @@ static HD HvCu hv_pw_accept(HvLds &S, const HevceImageDesc &im, int b) {
         S.ent[lvl].range = hv_ldc_i32(&m->range); S.ent[lvl].low = 0; S.ent[lvl].nbits = hv_ldc_i32(&m->nbits); S.ent[lvl].nbytes = 0; S.ent[lvl].bufbyte = 0; S.ent[lvl].zeros = 0; S.ent[lvl].nout = 0; S.ent[lvl].pad = 0;
         L.split_inc = hv_ldc_i32(&m->split_inc); L.ml = hv_ldc_i32(&m->ml); L.ma = hv_ldc_i32(&m->ma);
         S.cl_light = hv_ldc_i32(&m->pad_) == hv_xcc_id();          /* the chain workgroup sits on this XCD: light hand-offs from now on */
+        if (b == 2) {                                            /* the quad this 8x8 CU opens */
+            S.q8.y = cu.y; S.q8.x = cu.x; S.q8.ctu = ctu; S.q8.ml0 = L.ml; S.q8.ma0 = L.ma; S.q8.ml2 = hv_ldc_i32(&m->ml2); S.q8.ma2 = hv_ldc_i32(&m->ma2);
+            S.q8.L = hv_ldc_i32(&m->qL); S.q8.LB = hv_ldc_i32(&m->qLB); S.q8.A = hv_ldc_i32(&m->qA); S.q8.AR = hv_ldc_i32(&m->qAR);
+            S.cl_seq[2] += 1;                                    /* quads accepted */
+        }
     }
     if (tid < HEVCE_NCTXP) S.ent_ctx[lvl][tid] = (u8)hv_ldc_u8(&m->ctx[tid]);
     for (int p = tid; p < 1024; p += HV_NTHREADS) {                 /* source samples, edge-replicated  [ref :1620-1622] */
@@ -3084,6 +3112,38 @@ static HD HvCu hv_pw_accept(HvLds &S, const HevceImageDesc &im, int b) {
     BLOCK_SYNC();
     return cu;
 }
+/* 8x8 workgroup: CU m of the quad has been answered.  Its decision is the better of this workgroup's best candidate and the chain's NxN
+   candidate, the NxN one on equal cost (it has the highest index, hv_decide_cu)  [ref :1440, 1476, 1546-1556]; the chain workgroup
+   arrives at the same one with the same numbers.  The winner's samples, modes and coder state become the next CU's surroundings and
+   entry state  [ref :1364-1373].  Returns 0 when the report did not come (the picture is then flagged).  All threads. */
+static HD int hv_pw_advance8(HvLds &S, const HevceImageDesc &im, const HvCu cu, int m) {
+    const int tid = hv_tid(), k = hv_uni(S.cl_ans8);
+    HvLds::Level &L = S.lv[0];
+    HevceCluster *C = im.cluster;
+    if (tid == 0) { if (!hv_cl_wait(&C->nxn[k & 1].seq, k, &S.cl_fail, S.cl_light)) C->error = 2; }
+    BLOCK_SYNC();
+    if (hv_uni(S.cl_fail)) return 0;
+    const HevceNxn *r = &C->nxn[k & 1];
+    const int w = hv_min(hv_max(S.winner, 0), 69);
+    const int win70 = hv_ldc_i32(&r->cost) <= L.tcost[w];
+    HvGRec grec = (HvGRec)(hv_worker8_scratch(im, k) + HV_TL * 1024 * 2);
+    BLOCK_SYNC();                                                /* everyone has the decision before the entry state changes */
+    if (tid < 64) S.rec[cu.y + (tid >> 3) + 1][cu.x + (tid & 7) + HV_RX] = win70 ? (u8)hv_ldc_u8(&r->rec[tid]) : grec[w * 1024 + tid];
+    if (tid >= 64 && tid < 68) {
+        const int s = tid - 64, md = win70 ? (hv_ldc_i32(&r->modes) >> (8 * s)) & 0xff : (w < 35 ? w : w - 35);
+        S.q8.pm[2 * (m >> 1) + (s >> 1)][2 * (m & 1) + (s & 1)] = (u8)md;
+    }
+    if (tid == 128) { S.ent[0].range = win70 ? hv_ldc_i32(&r->range) : L.tregs[w].range; S.ent[0].nbits = win70 ? hv_ldc_i32(&r->nbits) : L.tregs[w].nbits - L.tnlog[w]; }
+    if (tid >= 256 && tid < 256 + HEVCE_NCTXP) S.ent_ctx[0][tid - 256] = win70 ? (u8)hv_ldc_u8(&r->ctx[tid - 256]) : L.tctx[tid - 256][w];
+    BLOCK_SYNC();
+    if (tid == 0) {                                              /* the next CU's neighbour modes  [ref :1369-1373] */
+        const int qy = 2 * ((m + 1) >> 1), qx = 2 * ((m + 1) & 1);
+        L.ml = qx > 0 ? S.q8.pm[qy][qx - 1] : (qy == 0 ? S.q8.ml0 : S.q8.ml2);
+        L.ma = qy > 0 ? S.q8.pm[qy - 1][qx] : (qx == 0 ? S.q8.ma0 : S.q8.ma2);
+    }
+    BLOCK_SYNC();
+    return 1;
+}
 /* The parent workgroup of a picture (cluster mode, second workgroup): it answers the chain workgroup's messages until told to
    exit.  16x16 CUs are answered at once (the chain needs them four rounds later); the 32x32 CU of a CTU, whose answer is due
    at the end of the CTU, is worked on stage by stage in between. */
@@ -3093,7 +3153,7 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
     BLOCK_SYNC();
     hv_init_tables(S, q, tid);
     hv_set_mode(S, 0, tid);
-    if (tid == 0) { S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_fail = 0; S.cl_pick = 0; S.cl_light = 0; S.cl_ok = 0; }
+    if (tid == 0) { S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_ans8 = 0; S.cl_fail = 0; S.cl_pick = 0; S.cl_light = 0; S.cl_ok = 0; }
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
     BLOCK_SYNC();
@@ -3131,16 +3191,39 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
             if (tid == 0 && b == 2) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[0] += n_ - wt_; wt_ = n_; S.prof2[5] += 1; }
 #endif
-            const HvCu cu = hv_pw_accept(S, im, b);
+            HvCu cu = hv_pw_accept(S, im, b);
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
             if (tid == 0 && b == 2) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[1] += n_ - wt_; wt_ = n_; }
 #endif
-            for (int st = 0; st < 3; st++) {
-                hv_pw_stage(S, im, cu, st, b == 2 ? lo8 : 0, b == 2 ? hi8 : 70, b == 2 ? slot8 : b);
+            /* a 16x16 CU: one answer.  An 8x8 message opens a quad: its four CUs one after the other, each entered with the decision
+               of the one before (hv_pw_advance8); the next message comes when the chain has decided the 16x16 CU around them */
+            int alive = 1;
+            for (int m8 = 0; m8 < (b == 2 ? 4 : 1) && alive; m8++) {
+                if (b == 2 && m8 > 0) {
+                    cu.y = S.q8.y + (m8 >> 1) * 8; cu.x = S.q8.x + (m8 & 1) * 8;
+                    hv_sub_avail(m8, S.q8.L, S.q8.LB, S.q8.A, S.q8.AR, cu.L, cu.LB, cu.A, cu.AR);
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
-                if (tid == 0 && b == 2) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[2 + st] += n_ - wt_; wt_ = n_; }
+                    if (tid == 0) S.prof2[5] += 1;
 #endif
+                }
+#ifdef HEVCE_EMU_DBG
+                if (b == 2 && tid == 0) { int cs = 0; for (int i = 0; i < HEVCE_NCTXP; i++) cs = cs * 31 + S.ent_ctx[0][i]; int rs = 0; for (int i = 0; i < 17; i++) rs = rs * 31 + (cu.A || cu.AR ? S.rec[cu.y][cu.x + HV_RX - 1 + (cu.AR ? i : (i > 8 ? 8 : i))] : 0); for (int j = 0; j < 16; j++) rs = rs * 31 + (cu.L || cu.LB ? S.rec[cu.y + 1 + (cu.LB ? j : (j > 7 ? 7 : j))][cu.x + HV_RX - 1] : 0);
+                    emu_dbg(1, S.cl_ans8 + 1, S.ent[0].range, S.ent[0].nbits, S.lv[0].ml, S.lv[0].ma, cs ^ rs, cu.L | cu.LB << 1 | cu.A << 2 | cu.AR << 3, cu.y * 100 + cu.x); }
+#endif
+                for (int st = 0; st < 3; st++) {
+                    hv_pw_stage(S, im, cu, st, b == 2 ? lo8 : 0, b == 2 ? hi8 : 70, b == 2 ? slot8 : b);
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+                    if (tid == 0 && b == 2) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[2 + st] += n_ - wt_; wt_ = n_; }
+#endif
+                }
+                if (b == 2 && m8 < 3) {
+                    alive = hv_pw_advance8(S, im, cu, m8);
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+                    if (tid == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[0] += n_ - wt_; wt_ = n_; }
+#endif
+                }
             }
+            if (!alive) break;
         } else {
             if (pick == 3) {
                 if (hv_ldc_i32(&C->msg[1].kind) == 2) break;
@@ -3203,7 +3286,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int force_exact = (im.flags & 1) || !im.payload;      /* without the writer nothing vouches for the FAST decisions */
     const int pk_nxn = (im.flags >> 8) & 0xff, pk_wr = (im.flags >> 16) & 0xff;
     hv_set_mode(S, force_exact, tid);
-    if (tid == 0) { S.poison = 0; S.nxv_pend = 0; S.poison_prev = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_fail = 0; S.cl_light = 0; S.cl_ok = 0; }
+    if (tid == 0) { S.poison = 0; S.nxv_pend = 0; S.poison_prev = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_ans8 = 0; S.cl_fail = 0; S.cl_light = 0; S.cl_ok = 0; }
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
     BLOCK_SYNC();
@@ -3288,7 +3371,13 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                         if (tid < 70) { S.lv[0].tdead[tid] = 1; S.lv[0].tpos[tid] = -1; }
                         if (tid == 0) S.l0_active = 1;
                         HV_PROFC(S, 5);                          /* since the last 8x8 decision: enclosing CUs' decisions and entries, snapshot, level begin */
-                        hv_cl_send(S, im, cu, ctu, 1);
+#ifdef HEVCE_EMU_DBG
+                        if (tid == 0) { int cs = 0; for (int i = 0; i < HEVCE_NCTXP; i++) cs = cs * 31 + S.ent_ctx[0][i];
+                            int rs = 0; for (int i = 0; i < 17; i++) rs = rs * 31 + (cu.A || cu.AR ? S.rec[cu.y][cu.x + HV_RX - 1 + (cu.AR ? i : (i > 8 ? 8 : i))] : 0); for (int j = 0; j < 16; j++) rs = rs * 31 + (cu.L || cu.LB ? S.rec[cu.y + 1 + (cu.LB ? j : (j > 7 ? 7 : j))][cu.x + HV_RX - 1] : 0);
+                            emu_dbg(0, S.cl_ans8 + 1, S.ent[0].range, S.ent[0].nbits, S.lv[0].ml, S.lv[0].ma, cs ^ rs, cu.L | cu.LB << 1 | cu.A << 2 | cu.AR << 3, cu.y * 100 + cu.x); }
+#endif
+                        if (m == 0) hv_cl_send(S, im, cu, ctu, 1, &c16);   /* opens the quad; the 8x8 workgroup finds its way through the other three CUs */
+                        else BLOCK_SYNC();
                         HV_PROFC(S, 6);
                     }
                     HV_PROF_T0();
@@ -3312,6 +3401,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                         if (k == 1 && m == 2) hv_level_contexts(S, im, c32);     /* its jobs ran in five phases up to this one */
                     }
                     if (!cl8) hv_engine_phase(S, im, cl ? 1 : (1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0)), 0);   /* cluster of 4: candidate 70 has been coded by its rider */
+                    else hv_cl_send_nxn(S, im);                  /* ... and the 8x8 workgroup may know it now */
                 }
                 hv_decide_cu(S, im, cu, ctu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr, cl + cl8);
                 if (cl && (cu.n == 16 || (cl8 && cu.n == 8))) hv_cl_store_rcon(S, im, cu, y0, x0);   /* the next CU's candidates elsewhere predict from these samples */

@@ -197,7 +197,6 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
            the chain workgroup's freed wavefronts help the NxN chain), 5 = candidates 0..34 / 35..69 on a workgroup each -- measured
            no faster than 4 (both halves' critical paths are the same passes), so 5 is only taken when asked for */
         j->cluster = !j->device_emit ? 1 : (4 * n8 <= cus ? 4 : (3 * n8 <= cus ? 3 : (2 * n8 <= cus ? 2 : 1)));
-        if (const char *e = getenv("HEVCE_CLUSTER")) if (atoi(e) == 5 && 5 * n8 <= cus && j->device_emit) j->cluster = 5;
         if (const char *e = getenv("HEVCE_CLUSTER")) { const int mx = atoi(e); if (mx >= 0 && mx < j->cluster) j->cluster = mx < 1 ? 1 : mx; }
     }
     if (getenv("HEVCE_DUMP")) {

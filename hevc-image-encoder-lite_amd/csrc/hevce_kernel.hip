@@ -5,9 +5,8 @@
 
 extern "C" __global__ void __launch_bounds__(HV_NTHREADS, 2)
 hevce_analyse_kernel(const HevceImageDesc *__restrict__ images, int nimages, int cluster) {
-    /* cluster mode: `cluster` (2 .. 5) workgroups per picture -- the first walks the picture's chain of decisions, the others
-       evaluate candidates for it: the 16x16 / 32x32 CUs (one workgroup for both levels, or one each), with four also the 8x8 CUs'
-       (five: candidates 0..34 and 35..69 on a workgroup each) */
+    /* cluster mode: `cluster` (2 .. 4) workgroups per picture -- the first walks the picture's chain of decisions, the others
+       evaluate candidates for it: the 16x16 / 32x32 CUs (one workgroup for both levels, or one each), with four also the 8x8 CUs' */
     /* the workgroups of a picture get block ids that are equal modulo 8: consecutive ids go round the 8 XCDs, so a cluster sits
        on one XCD and shares its L2 (hand-offs without L2 maintenance; checked at run time, hevce_device.h hv_publish_fence) */
     const int b = blockIdx.x, npad = (nimages + 7) & ~7;
@@ -15,7 +14,7 @@ hevce_analyse_kernel(const HevceImageDesc *__restrict__ images, int nimages, int
     if (pic >= nimages) return;
     const HevceImageDesc im = images[pic];
     if (role == 0) hv_analyse_image(HV_S, im);
-    else if (role >= 3) hv_parent_worker(HV_S, im, 4, (cluster >= 5 && role == 4) ? 35 : 0, (cluster >= 5 && role == 3) ? 35 : 70, role == 4 ? 3 : 2);
+    else if (role >= 3) hv_parent_worker(HV_S, im, 4, 0, 70, 2);
     else hv_parent_worker(HV_S, im, cluster == 2 ? 3 : role, 0, 70, 2);
 }
 
