@@ -302,6 +302,7 @@ struct alignas(16) HvLds {
     struct WrSt {                                           /* where the writer's coder stands in that CTU's token slots (hv_wr_engine works in slices) */
         int pos, ci, done;                                  /* next slot in coding order (3 per 4x4 z-position: CU header, block header, group), chunk inside it; CTU complete */
         int total, budget;                                  /* chunks of the CTU, chunks per slice */
+        int tpc, used;                                      /* 256 x the 100 MHz ticks the coder took per chunk in its last slice; chunks of the CTU coded so far */
     } wst;
 #ifdef HEVCE_ANYPROF
     unsigned long long prof[3][8];
@@ -2467,7 +2468,8 @@ static HDN void hv_wr_tokenise(const HevceImageDesc &im, int cw) {
     if (lane == 0) {
         int total = 0;
         for (int i = 0; i < 64; i++) total += W.cnt[0][i] + W.cnt[1][i] + W.cnt[2][i];
-        S.wst.pos = 0; S.wst.ci = 0; S.wst.done = 0; S.wst.total = total; S.wst.budget = (total + 14) / 15;
+        S.wst.pos = 0; S.wst.ci = 0; S.wst.done = 0; S.wst.total = total; S.wst.budget = (total + 14) / 15; S.wst.used = 0;
+        if (cw <= 0) S.wst.tpc = 25600;                           /* first guess: 100 ticks (about 2.2 k cycles) per chunk */
     }
 }
 /* The writer's coder: `budget` chunks of CTU cw's tokens, in coding order, through the exact byte-emitting coder; after the
@@ -2526,6 +2528,10 @@ static HDN void hv_wr_engine(const HevceImageDesc &im_, int cw, int budget) {
     HV_WR_SEEK();
     HvChunk nxt = { 0, 0, 0, 0 };
     if (pos < 192) nxt = *HV_WR_ADDR();
+#ifndef HEVCE_EMU
+    const unsigned long long ts_ = hv_realtime();
+#endif
+    const int budget0 = budget;
     while (pos < 192 && budget > 0) {
         unsigned c4[4];
 #pragma unroll
@@ -2593,8 +2599,11 @@ static HDN void hv_wr_engine(const HevceImageDesc &im_, int cw, int budget) {
     }
     HV_LT_EACH(cxa, l_, v_, S.nxn_ctx[l_][HV_TL - 1] = (u8)v_);
     HV_LT_EACH(cxb, l_, v_, if (64 + l_ < HEVCE_NCTXP) S.nxn_ctx[64 + l_][HV_TL - 1] = (u8)v_);
+#ifndef HEVCE_EMU
+    if (lane0 && budget0 - budget >= 4) T.tpc = (int)(((hv_realtime() - ts_) << 8) / (unsigned)(budget0 - budget));
+#endif
     if (lane0) {
-        T.pos = pos; T.ci = ci; T.done = done;
+        T.pos = pos; T.ci = ci; T.done = done; T.used += budget0 - budget;
         S.wr.range = w.range; S.wr.low = w.low; S.wr.nbits = w.nbits; S.wr.nbytes = w.pending; S.wr.bufbyte = w.held; S.wr.zeros = w.zeros; S.wr.nout = w.n; S.wr.pad = 0;
         S.wr_epb = w.epb;
     }
@@ -2630,7 +2639,20 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
            the writer is wavefront 7 (measured: on wavefront 4 its slice, 91 k cycles, outlasted the NxN chain's 79 k and took issue
            slots from it), wavefront 4 idles and the NxN chain has its SIMD to itself; the tile in ws[4] stays the writer's */
         if (wr_on) {
+            const unsigned long long t0 = hv_realtime();
             if (k16 == 0 && m == 0) { hv_wr_stage(S, im, ctu - 1); WAVE_SYNC(); hv_wr_tokenise(im, ctu - 1); WAVE_SYNC(); }
+#ifndef HEVCE_EMU
+            /* cluster of four: this wavefront's slice is what ends the jobs phase when it outlasts the NxN chain, and equal shares of the
+               CTU's chunks over fifteen rounds did (87 k cycles against 81 k; the first round, with the binarisation, 133 k; the last
+               one idle).  So: equal shares of the TIME over all sixteen rounds -- the binarisation counted at what it took, the chunks
+               at the pace of the last slice (100 MHz ticks, x 256) */
+            if (hv_uni(cl) == 2) {
+                const int r = k16 * 4 + m, tpc = hv_max(hv_uni(S.wst.tpc), 64), total = hv_uni(S.wst.total), left = total - hv_uni(S.wst.used);
+                int budget = (left + 15 - r) / (16 - r);
+                if (r == 0) { const long long tok = (long long)(hv_realtime() - t0) << 8; budget = (int)(((tok + (long long)total * tpc) / 16 - tok) / tpc); }
+                hv_wr_engine(im, ctu - 1, r == 15 ? 100000 : hv_max(budget, 1));
+            } else
+#endif
             hv_wr_engine(im, ctu - 1, (k16 * 4 + m) == 15 ? 100000 : S.wst.budget);
         }
         return;
@@ -2691,6 +2713,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
 }
 
 static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu);
+static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu cu, HevceRecord *rec);
 static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, HevceRecord *rec, int32_t *dump, int cl) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, n = cu.n;
     HvLds::Level &L = S.lv[cu.lvl];
@@ -2700,6 +2723,7 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
     const int ntrials = (n == 8) ? 71 : 70;
     const int my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
     HV_PROF_T0();
+    if (n == 8 && cl == 2 && !dump) { hv_decide8_cluster(S, im, cu, rec); HV_PROF(S, 0, 4); return; }   /* the same decision and commit, in two barriers */
     if (n == 8 && cl == 2) { HV_PROFC(S, -1); hv_cl_receive(S, im, cu); HV_PROFC(S, 1); }   /* cluster of 4: candidates 0..69 were evaluated elsewhere, the best of them joins candidate 70 */
     if (n > 8) {
         /* the split alternative is the state the children left behind  [ref :1409-1410]; it also bounds the pruning */
@@ -2984,6 +3008,63 @@ static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu) 
     if (tid < HEVCE_NCTXP) L.tctx[tid][w] = (u8)hv_ldc_u8(&r->ctx[tid]);
     BLOCK_SYNC();
 }
+/* chain workgroup, cluster of four, decision of an 8x8 CU: hv_cl_receive + the arg-min + the commit of hv_decide_cu for the two
+   candidates there are -- the 8x8 workgroup's best (its answer) and the NxN candidate, number 70, which wins on equal cost (highest
+   index, [ref :1440, 1476]) -- with every thread working the decision out for itself, so that the wait for the answer is followed by
+   one barrier instead of five.  All threads. */
+static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu cu, HevceRecord *rec) {
+    const int tid = hv_tid();
+    HvLds::Level &L = S.lv[0];
+    const int k = hv_uni(S.cl_ans8), slot = 2 + (k & 1);         /* this CU's number (hv_cl_send_nxn) */
+    HV_PROFC(S, -1);
+    if (tid == 0) {
+        const unsigned long long to = (im.flags & 4) ? 100000ull : HV_CL_TIMEOUT;   /* test hook, see hv_cl_receive */
+        if (!hv_cl_wait(&im.cluster->res[slot].seq, k, &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
+        HV_PROFC(S, 0);
+    }
+    BLOCK_SYNC();
+    const HevceRes *r = &im.cluster->res[slot];
+    const int wa = hv_min(hv_max(hv_ldc_i32(&r->winner), 0), 69);
+    const int win70 = L.tcost[70] <= hv_ldc_i32(&r->cost);
+    const int w = win70 ? 70 : wa;
+    HV_GLOBAL u8 *scr = hv_worker8_scratch(im, k);
+    HvGLev glev = (HvGLev)scr;
+    HvGRec grec = (HvGRec)(scr + HV_TL * 1024 * 2);
+    if (tid == 0) {
+        S.winner = w;
+        if (win70) { S.com = L.tregs[70]; S.com.nbits -= L.tnlog[70]; }
+        else { S.com = S.ent[0]; S.com.range = hv_ldc_i32(&r->range); S.com.nbits = hv_ldc_i32(&r->nbits); }
+        const int ok = S.cl_ok | (hv_ldc_i32(&r->pad_[0]) == 1 ? 4 : 0);   /* all of the cluster on this XCD: light hand-offs (hv_cl_receive) */
+        S.cl_ok = ok;
+        if ((ok & 7) == 7) S.cl_light = 1;
+    }
+    if (tid >= 64 && tid < 64 + HEVCE_NCTXP) S.com_ctx[tid - 64] = win70 ? L.tctx[tid - 64][70] : (u8)hv_ldc_u8(&r->ctx[tid - 64]);
+    const int kindw = w < 35 ? 0 : (w < 70 ? 1 : 2);
+    if (tid >= 256 && tid < 320) {
+        const int p = tid - 256, yy = p >> 3, xx = p & 7;
+        S.rec[cu.y + yy + 1][cu.x + xx + HV_RX] = (kindw == 2) ? S.nxn_crec[yy][xx] : (u8)hv_ldc_u8((const u8 *)(grec + w * 1024 + p));
+        int lv;
+        if (kindw == 0) lv = hv_ldc_i16((const short *)(glev + w * 1024 + hv_scan_idx(S, 3, hv_scan_kind(8, w), yy, xx)));
+        else {
+            const int s4 = (yy >= 4) * 2 + (xx >= 4);
+            const int md = kindw == 1 ? w - 35 : S.nxn_modes[s4];
+            const int si = hv_scan_idx(S, 2, hv_scan_kind(4, md), yy & 3, xx & 3);
+            lv = kindw == 1 ? hv_ldc_i16((const short *)(glev + w * 1024 + s4 * 16 + si)) : S.nxn_bestlev[s4][si];
+        }
+        rec->lev[cu.y + yy][cu.x + xx] = (short)lv;
+    }
+    if (tid >= 384 && tid < 388) {
+        const int i = (tid - 384) >> 1, jx = (tid - 384) & 1, my = 1 + (cu.y >> 2), mx = 1 + (cu.x >> 2);
+        const int md = kindw == 0 ? w : kindw == 1 ? w - 35 : S.nxn_modes[i * 2 + jx];
+        S.map_cu[my + i][mx + jx] = 8;
+        S.map_pm[my + i][mx + jx] = (u8)md;
+        rec->mode[(cu.y >> 2) + i][(cu.x >> 2) + jx] = (u8)md;
+        rec->info[(cu.y >> 2) + i][(cu.x >> 2) + jx] = (u8)(0 | (kindw == 2 ? HEVCE_INFO_NXN : 0) | (kindw == 1 ? HEVCE_INFO_TUSPLIT : 0));
+    }
+    BLOCK_SYNC();
+    HV_PROFC(S, 3);
+}
+/* the samples of a CU that has just been decided go to the picture's reconstruction at once (the parents of the NEXT CUs read them there) */
 static HD void hv_cl_store_rcon(HvLds &S, const HevceImageDesc &im, const HvCu cu, int y0, int x0) {
     for (int p = hv_tid(); p < cu.n * cu.n; p += HV_NTHREADS) {
         const int yy = cu.y + p / cu.n, xx = cu.x + p % cu.n;
@@ -3206,10 +3287,6 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
                     if (tid == 0) S.prof2[5] += 1;
 #endif
                 }
-#ifdef HEVCE_EMU_DBG
-                if (b == 2 && tid == 0) { int cs = 0; for (int i = 0; i < HEVCE_NCTXP; i++) cs = cs * 31 + S.ent_ctx[0][i]; int rs = 0; for (int i = 0; i < 17; i++) rs = rs * 31 + (cu.A || cu.AR ? S.rec[cu.y][cu.x + HV_RX - 1 + (cu.AR ? i : (i > 8 ? 8 : i))] : 0); for (int j = 0; j < 16; j++) rs = rs * 31 + (cu.L || cu.LB ? S.rec[cu.y + 1 + (cu.LB ? j : (j > 7 ? 7 : j))][cu.x + HV_RX - 1] : 0);
-                    emu_dbg(1, S.cl_ans8 + 1, S.ent[0].range, S.ent[0].nbits, S.lv[0].ml, S.lv[0].ma, cs ^ rs, cu.L | cu.LB << 1 | cu.A << 2 | cu.AR << 3, cu.y * 100 + cu.x); }
-#endif
                 for (int st = 0; st < 3; st++) {
                     hv_pw_stage(S, im, cu, st, b == 2 ? lo8 : 0, b == 2 ? hi8 : 70, b == 2 ? slot8 : b);
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
@@ -3279,6 +3356,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
 #endif
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     const unsigned long long prof_start_ = __builtin_amdgcn_s_memtime();
+    if (tid == 0) S.prof_pt = prof_start_;
 #endif
     BLOCK_SYNC();
     HV_TRACE(S, 0, 1);
@@ -3365,17 +3443,12 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                 if (cu.n == 8) {
                     hv_snapshot(S, 0, tid);
                     hv_level_begin(S, cu);
-                    BLOCK_SYNC();
-                    if (cl8) {
+                    if (!cl8) BLOCK_SYNC();
+                    else {                                       /* (no barrier needed first: every thread below reads what it wrote itself above) */
                         /* the candidates of this CU other than the NxN one are another workgroup's: only candidate 70 runs here */
                         if (tid < 70) { S.lv[0].tdead[tid] = 1; S.lv[0].tpos[tid] = -1; }
                         if (tid == 0) S.l0_active = 1;
                         HV_PROFC(S, 5);                          /* since the last 8x8 decision: enclosing CUs' decisions and entries, snapshot, level begin */
-#ifdef HEVCE_EMU_DBG
-                        if (tid == 0) { int cs = 0; for (int i = 0; i < HEVCE_NCTXP; i++) cs = cs * 31 + S.ent_ctx[0][i];
-                            int rs = 0; for (int i = 0; i < 17; i++) rs = rs * 31 + (cu.A || cu.AR ? S.rec[cu.y][cu.x + HV_RX - 1 + (cu.AR ? i : (i > 8 ? 8 : i))] : 0); for (int j = 0; j < 16; j++) rs = rs * 31 + (cu.L || cu.LB ? S.rec[cu.y + 1 + (cu.LB ? j : (j > 7 ? 7 : j))][cu.x + HV_RX - 1] : 0);
-                            emu_dbg(0, S.cl_ans8 + 1, S.ent[0].range, S.ent[0].nbits, S.lv[0].ml, S.lv[0].ma, cs ^ rs, cu.L | cu.LB << 1 | cu.A << 2 | cu.AR << 3, cu.y * 100 + cu.x); }
-#endif
                         if (m == 0) hv_cl_send(S, im, cu, ctu, 1, &c16);   /* opens the quad; the 8x8 workgroup finds its way through the other three CUs */
                         else BLOCK_SYNC();
                         HV_PROFC(S, 6);
@@ -3401,11 +3474,12 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                         if (k == 1 && m == 2) hv_level_contexts(S, im, c32);     /* its jobs ran in five phases up to this one */
                     }
                     if (!cl8) hv_engine_phase(S, im, cl ? 1 : (1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0)), 0);   /* cluster of 4: candidate 70 has been coded by its rider */
-                    else hv_cl_send_nxn(S, im);                  /* ... and the 8x8 workgroup may know it now */
+                    else { HV_PROFC(S, -1); hv_cl_send_nxn(S, im); HV_PROFC(S, 1); }   /* ... and the 8x8 workgroup may know it now */
                 }
                 hv_decide_cu(S, im, cu, ctu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr, cl + cl8);
                 if (cl && (cu.n == 16 || (cl8 && cu.n == 8))) hv_cl_store_rcon(S, im, cu, y0, x0);   /* the next CU's candidates elsewhere predict from these samples */
                 if (cl8 && cu.n == 8) HV_PROFC(S, 4);
+                if (cl8 && cu.n > 8) HV_PROFC(S, 2);             /* decisions of the enclosing CUs */
             }
 
         }

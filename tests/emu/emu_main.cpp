@@ -68,13 +68,6 @@ void emu_block_sync(void) {
 }
 
 long long emu_tok_stat[4];
-static int dbg_log[2][100000][7];
-void emu_dbg(int who, int k, int a, int b, int c, int d, int e, int f, int g) {
-    int *r = dbg_log[who][k % 100000]; r[0] = a; r[1] = b; r[2] = c; r[3] = d; r[4] = e; r[5] = f; r[6] = g;
-    const int *o = dbg_log[who ^ 1][k % 100000];
-    if (o[0] && memcmp(o, r, sizeof(int) * 7)) fprintf(stderr, "emu_dbg: CU %d differs: chain/worker range %d/%d nbits %d/%d ml %d/%d ma %d/%d ctx %d/%d avail %d/%d pos %d/%d\n", k,
-        dbg_log[0][k][0], dbg_log[1][k][0], dbg_log[0][k][1], dbg_log[1][k][1], dbg_log[0][k][2], dbg_log[1][k][2], dbg_log[0][k][3], dbg_log[1][k][3], dbg_log[0][k][4], dbg_log[1][k][4], dbg_log[0][k][5], dbg_log[1][k][5], dbg_log[0][k][6], dbg_log[1][k][6]);
-}
 extern "C" __attribute__((visibility("default")))
 int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, uint8_t *records, int32_t *ctu_state, int32_t *dump,
                 uint8_t *payload, int32_t *payload_len, int flags, int32_t *stats, int cluster) {

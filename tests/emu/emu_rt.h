@@ -6,8 +6,7 @@
  * product library; the product has no CPU path.
  */
 #pragma once
-extern long long emu_tok_stat[4];
-void emu_dbg(int who, int k, int a, int b, int c, int d, int e, int f, int g);   /* FAST trial slots: tokens, chunks, slots (diagnostics) */
+extern long long emu_tok_stat[4];   /* FAST trial slots: tokens, chunks, slots (diagnostics) */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>

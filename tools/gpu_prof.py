@@ -45,8 +45,8 @@ if kind == "phases":
             print("    wavefront %d (%s): block jobs %.1f, binarise %.1f, engines %.1f" % (wv, "TU-split chains, 16 modes" if wv < 3 else "single blocks, 8 modes", pw[wv, 0], pw[wv, 1], pw[wv, 2]))
     if wk[5] > 0:
         hs = p2[5:12] / nctu / 16 / 1e3
-        print("  chain workgroup between two 8x8 jobs phases, k cycles per round: wait for the answer %.1f, take it over %.1f, arg-min %.1f, commit %.1f, "
-              "samples to HBM %.1f, up to the next CU's message %.1f, send %.1f" % tuple(hs))
+        print("  chain workgroup between two 8x8 jobs phases, k cycles per round: NxN report %.1f, wait for the answer %.1f, decision + commit %.1f, samples to HBM %.1f, "
+              "enclosing CUs' decisions %.1f, entering the next CU (snapshot, level begin, CTU start / end work) %.1f, quad message or barrier %.1f" % (hs[1], hs[0], hs[3], hs[4], hs[2], hs[5], hs[6]))
     print("  NxN chain:", "  ".join(f"{nm} {100.0*p2[i]/tot:5.1f}%" for i, nm in enumerate(("4x4 pipelines", "tokenise", "engine", "select", "tail"))))
 elif kind == "nxn":
     stages = nctu * 64
