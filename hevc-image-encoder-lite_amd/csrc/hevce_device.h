@@ -2921,14 +2921,20 @@ static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q) {
 }
 
 /* --------------------------------------------------------------------------------------------- */
-/* Cluster mode: TWO workgroups per picture.  The chain workgroup (hv_analyse_image) keeps what is serial -- the sixteen 8x8 CUs  */
-/* of a CTU, one after the other, their NxN chains, the commits, the stream writer -- and hands every 16x16 / 32x32 CU to the      */
-/* parent workgroup (hv_parent_worker, on another compute unit) at the moment the CU is ENTERED: its 70 candidates start from the  */
-/* entry snapshot and read only samples outside the CU  [ref :1364-1365, 1420-1424], so they are independent of everything the    */
+/* Cluster mode: TWO to FOUR workgroups per picture.  The chain workgroup (hv_analyse_image) keeps what is serial -- the sixteen   */
+/* 8x8 CUs of a CTU, one after the other, their NxN chains, the commits, the stream writer -- and hands every 16x16 / 32x32 CU to   */
+/* a parent workgroup (hv_parent_worker, on another compute unit) at the moment the CU is ENTERED: its 70 candidates start from    */
+/* the entry snapshot and read only samples outside the CU  [ref :1364-1365, 1420-1424], so they are independent of everything the */
 /* chain does until the CU's decision, four (sixteen) rounds later.  Back comes the best unsplit candidate; the chain compares it  */
-/* with the split alternative and commits.  Hand-off through HBM (HevceCluster): sequence words with release / acquire at agent   */
-/* scope, every wait bounded (a partner that is not resident must not hang the GPU: the picture is then flagged and the host      */
-/* encodes it again without a cluster).  EXACT CTUs (re-analysis) are done by the chain workgroup alone, as without a cluster.     */
+/* with the split alternative and commits.  Clusters of four: a fourth workgroup evaluates candidates 0..69 of the 8x8 CUs too     */
+/* (the chain keeps the NxN candidate, number 70).  It is on the critical path, so it gets ONE message per 16x16 quad and walks    */
+/* the quad's four CUs on its own: after its answer for a CU it takes the chain's report of the NxN candidate (hv_cl_send_nxn),     */
+/* makes the CU's decision itself -- the chain makes the same one from the same numbers -- and enters the next CU with the winner's */
+/* samples, modes, coder and contexts (hv_pw_advance8) while the chain is still committing.  Answers, reports and the 8x8          */
+/* candidates' trial scratch are double-buffered by the parity of the CU's number, so neither side can overwrite what the other     */
+/* still reads.  Hand-off through HBM (HevceCluster): sequence words, light or agent-scope fences (hv_publish_fence), every wait    */
+/* bounded (a partner that is not resident must not hang the GPU: the picture is then flagged and the host encodes it again        */
+/* without a cluster).  EXACT CTUs (re-analysis) are done by the chain workgroup alone, as without a cluster.                      */
 /* --------------------------------------------------------------------------------------------- */
 #define HV_CL_BOX(lvl) (((lvl) + 2) % 3)                    /* mailbox of a CU level: 16x16 -> 0, 32x32 -> 1, 8x8 -> 2 */
 #define HV_CL_TIMEOUT 3000000000ull                          /* 30 s of the 100 MHz clock */

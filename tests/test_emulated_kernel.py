@@ -63,7 +63,7 @@ def test_emulated_kernel_reanalysis_paths(path, flags):
 @pytest.mark.parametrize("flags", [0, 2 << 8, 3 << 16], ids=["fast", "nxn2", "wr3"])
 @pytest.mark.parametrize("path", MODE_CASES, ids=lambda p: os.path.basename(p)[6:-4])
 def test_emulated_cluster_of_workgroups(path, flags, nwg):
-    """cluster mode (hevce_device.h hv_parent_worker): the chain workgroup and the parent workgroup(s) of one picture as 2 / 3 x 512
+    """cluster mode (hevce_device.h hv_parent_worker): the chain workgroup and the parent workgroup(s) of one picture as 2 / 3 / 4 x 512
     fibers exchanging messages through the HevceCluster mailboxes; also with re-analysed CTUs, which the chain workgroup does alone."""
     import emu
     c = load_case(path)
