@@ -9,8 +9,8 @@ CTUS = 510                                                     # 960x544 PMC wor
 
 
 def db(sub):
-    f = glob.glob(os.path.join(G, sub, "*", "*.db"))
-    return sqlite3.connect(f[0]) if f else None
+    f = sorted(glob.glob(os.path.join(G, sub, "*", "*.db")), key=os.path.getmtime)    # gpurun merges passes into the same directory: the newest
+    return sqlite3.connect(f[-1]) if f else None
 
 
 def json_line(path):
