@@ -2712,6 +2712,17 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, (m >= 2 ? 2 : 0) | (k16 >= 2 ? 4 : 0), &S.nxn_busy, 6, w1);
 }
 
+/* cluster mode (described further down): mailbox numbering and the bounded wait */
+#define HV_CL_BOX(lvl) (((lvl) + 2) % 3)                    /* mailbox of a CU level: 16x16 -> 0, 32x32 -> 1, 8x8 -> 2 */
+#define HV_CL_TIMEOUT 3000000000ull                          /* 30 s of the 100 MHz clock */
+static HD int hv_cl_wait(const int *seq, int want, int *fail, int light, unsigned long long timeout = HV_CL_TIMEOUT) {   /* one thread */
+    const unsigned long long t0 = hv_realtime();
+    for (;;) {
+        if (hv_ld_flag(seq) == want) { hv_acquire_fence(light); return 1; }
+        if (*fail || hv_realtime() - t0 > timeout) { *fail = 1; return 0; }   /* after one failure the picture is lost anyway: no more waiting */
+        hv_spin_pause();
+    }
+}
 static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu);
 static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu cu, HevceRecord *rec);
 static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, HevceRecord *rec, int32_t *dump, int cl) {
@@ -2725,7 +2736,33 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
     HV_PROF_T0();
     if (n == 8 && cl == 2 && !dump) { hv_decide8_cluster(S, im, cu, rec); HV_PROF(S, 0, 4); return; }   /* the same decision and commit, in two barriers */
     if (n == 8 && cl == 2) { HV_PROFC(S, -1); hv_cl_receive(S, im, cu); HV_PROFC(S, 1); }   /* cluster of 4: candidates 0..69 were evaluated elsewhere, the best of them joins candidate 70 */
-    if (n > 8) {
+    const int lean = n > 8 && cl && !dump;
+    if (lean) {
+        /* cluster: two alternatives, the parent workgroup's best unsplit candidate and the split the children left behind, which
+           any candidate of equal cost beats (index -1 in the arg-min below)  [ref :1409-1410, 1440]: hv_cl_receive + the arg-min,
+           every thread for itself, in two barriers instead of five */
+        const int b = HV_CL_BOX(cu.lvl);
+        if (hv_uni(wave) == 0) hv_job_sse(S, lane, cu);
+        if (tid == 0) {
+            const unsigned long long to = (im.flags & 4) ? 100000ull : HV_CL_TIMEOUT;   /* test hook, see hv_cl_receive */
+            if (!hv_cl_wait(&im.cluster->res[b].seq, S.cl_seq[b], &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
+        }
+        BLOCK_SYNC();
+        const HevceRes *r = &im.cluster->res[b];
+        const int wa = hv_min(hv_max(hv_ldc_i32(&r->winner), 0), 69);
+        const int csplit = hv_rdcost(q, S.split_sse, hv_regs_bits(S.com) - hv_regs_bits(S.ent[cu.lvl]));
+        const int wl = hv_ldc_i32(&r->cost) <= csplit ? wa : -1;
+        if (tid == 0) {
+            S.winner = wl;
+            L.tregs[wa] = S.ent[cu.lvl]; L.tregs[wa].range = hv_ldc_i32(&r->range); L.tregs[wa].nbits = hv_ldc_i32(&r->nbits); L.tnlog[wa] = 0;
+            const int ok = S.cl_ok | (hv_ldc_i32(&r->pad_[0]) == 1 ? 1 << b : 0);
+            S.cl_ok = ok;
+            if ((ok & (im.cluster->size <= 3 ? 3 : 7)) == (im.cluster->size <= 3 ? 3 : 7)) S.cl_light = 1;
+        }
+        if (wl >= 0 && tid >= 64 && tid < 64 + HEVCE_NCTXP) L.tctx[tid - 64][wa] = (u8)hv_ldc_u8(&r->ctx[tid - 64]);
+        BLOCK_SYNC();
+    }
+    if (n > 8 && !lean) {
         /* the split alternative is the state the children left behind  [ref :1409-1410]; it also bounds the pruning */
         if (hv_uni(wave) == 0) hv_job_sse(S, lane, cu);
         BLOCK_SYNC();
@@ -2743,7 +2780,7 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
         d[0] = v ? L.tsse[tid] : 0; d[1] = v ? L.tcost[tid] : 0; d[2] = v ? L.tdead[tid] : 0; d[3] = v ? L.tlen[tid] : 0;
     }
     /* ---------------- arg-min in the reference's order, later candidate wins ties ---------------- */
-    if (hv_uni(wave) == 0) {
+    if (!lean && hv_uni(wave) == 0) {
         /* key = (cost, index): lowest cost, the highest index among equals [ref :1440 adopts on >=]; the split alternative
            takes part as index -1 (any candidate of equal cost beats it); -2 = nothing yet.  Two candidates per lane, then a
            butterfly over the wavefront. */
@@ -2764,7 +2801,7 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
         }
         if (lane == 0) S.winner = bi < 0 ? -1 : bi;
     }
-    BLOCK_SYNC();
+    if (!lean) BLOCK_SYNC();
     const int w = S.winner;
     HV_PROF(S, cu.lvl, 3);
     if (n == 8 && cl == 2) HV_PROFC(S, 2);
@@ -2936,16 +2973,6 @@ static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q) {
 /* bounded (a partner that is not resident must not hang the GPU: the picture is then flagged and the host encodes it again        */
 /* without a cluster).  EXACT CTUs (re-analysis) are done by the chain workgroup alone, as without a cluster.                      */
 /* --------------------------------------------------------------------------------------------- */
-#define HV_CL_BOX(lvl) (((lvl) + 2) % 3)                    /* mailbox of a CU level: 16x16 -> 0, 32x32 -> 1, 8x8 -> 2 */
-#define HV_CL_TIMEOUT 3000000000ull                          /* 30 s of the 100 MHz clock */
-static HD int hv_cl_wait(const int *seq, int want, int *fail, int light, unsigned long long timeout = HV_CL_TIMEOUT) {   /* one thread */
-    const unsigned long long t0 = hv_realtime();
-    for (;;) {
-        if (hv_ld_flag(seq) == want) { hv_acquire_fence(light); return 1; }
-        if (*fail || hv_realtime() - t0 > timeout) { *fail = 1; return 0; }   /* after one failure the picture is lost anyway: no more waiting */
-        hv_spin_pause();
-    }
-}
 /* chain workgroup: the CU of level lvl is entered (S.ent / S.ent_ctx / S.lv[lvl] hold its entry state): tell the parent workgroup.
    All threads; what the parents read of the picture's reconstruction has been stored by now (fence below). */
 static HD void hv_cl_send(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, int kind, const HvCu *quad = nullptr) {   /* quad: the 16x16 CU an 8x8 message opens */
