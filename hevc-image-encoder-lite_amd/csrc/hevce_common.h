@@ -75,6 +75,7 @@ typedef struct HevceRes {      /* parent workgroup -> analysis workgroup: the be
     int32_t range, nbits;      /* coder after it (nbits with its bypass bins taken off) */
     int32_t pad_[2];
     uint8_t ctx[104];          /* contexts after it */
+    uint64_t tag;              /* 8x8 answers: cost << 32 | (seq & 0xffffff) << 8 | winner, one 64-bit store after everything else: whoever polls it has the decision's inputs in the same load */
 } HevceRes;
 typedef struct HevceNxn {      /* analysis workgroup -> 8x8 workgroup, once per 8x8 CU: the CU's NxN candidate (number 70), which only the chain knows */
     int32_t seq;               /* number of the 8x8 CU since the launch, written last (release) */

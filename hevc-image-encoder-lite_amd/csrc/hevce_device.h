@@ -28,6 +28,8 @@ static inline void hv_publish_fence(int) { }
 static inline void hv_acquire_fence(int) { }
 static inline void hv_st_flag(int *p, int v) { *p = v; }
 static inline int  hv_ld_flag(const int *p) { return *p; }
+static inline void hv_st_flag64(unsigned long long *p, unsigned long long v) { *p = v; }
+static inline unsigned long long hv_ld_flag64(const unsigned long long *p) { return *p; }
 static inline int  hv_xcc_id() { return 0; }
 static inline void hv_spin_pause() { emu_yield(); }           /* lets the other workgroup's fibers run */
 static inline void hv_spin_short() { emu_yield(); }
@@ -116,6 +118,8 @@ static HD void hv_publish_fence(int light) {
 static HD void hv_acquire_fence(int light) { if (!light) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 static HD void hv_st_flag(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static HD int  hv_ld_flag(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static HD void hv_st_flag64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static HD unsigned long long hv_ld_flag64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static HD int  hv_xcc_id() { int v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 15; }
 static HD void hv_spin_pause() { __builtin_amdgcn_s_sleep(2); }   /* between two polls of a word in HBM: 128 cycles (a hand-off is on the critical path) */
 static HD void hv_spin_short() { __builtin_amdgcn_s_sleep(1); }   /* between two polls of an LDS flag */
@@ -281,7 +285,12 @@ struct alignas(16) HvLds {
     /* control */
     int cl_seq[3];                                          /* cluster mode: messages sent (chain workgroup) / answered (parent workgroup) per mailbox; 8x8 worker: quads accepted */
     int cl_ans8;                                            /* 8x8 CUs reported (chain workgroup) / answered (8x8 workgroup) since the launch */
-    struct Quad8 { int ctu; u8 y, x, L, LB, A, AR, ml0, ml2, ma0, ma2, pad_[2]; u8 pm[4][4]; } q8;   /* 8x8 workgroup: the quad it is walking */
+    struct Quad8 { int ctu; u8 y, x, L, LB, A, AR, ml0, ml2, ma0, ma2, pad_[2]; u8 pm[4][4]; };
+    struct Peek8 { int k, w, cost; };
+    union {
+        Quad8 q8;                                           /* 8x8 workgroup: the quad it is walking */
+        Peek8 pf;                                           /* chain workgroup: the answer to 8x8 CU pf.k has been seen (hv_cl_peek8): its winner and cost */
+    };
     int cl_pick, cl_fail;                                   /* parent workgroup: the mailbox to serve next (-1 exit); a hand-off timed out */
     int cl_light, cl_ok;                                    /* all partners share this workgroup's XCD (light hand-offs, see hv_publish_fence); chain workgroup: answer slots whose sender said so */
     int exact;                                              /* 1: EXACT engines (the reference's bit counts by construction); 0: FAST (see hv_fengine_chunk) */
@@ -2617,6 +2626,25 @@ static HDN void hv_wr_engine(const HevceImageDesc &im_, int cw, int budget) {
      3. in the time the NxN chain still takes, the prepared candidates of the enclosing CUs ride on.
    The schedule is static and wave-uniform (SGPRs): no lane-dependent control flow may surround the jobs (wave shuffles). */
 #define HV_JOBT(slot, call) call
+/* Cluster of four: the 8x8 workgroup's answer arrives a few thousand cycles before the NxN chain ends.  Wavefront 4, idle in that
+   mode, watches for it during the jobs phase, so that the decision does not begin with a round trip to the L2 for a flag that has
+   long been set, and a second one for the cost and the winner: both come with the flag (HevceRes.tag).  Gives up when the chain
+   is through. */
+static HD void hv_cl_peek8(HvLds &S, const HevceImageDesc &im, int lane) {
+    if (lane) return;
+    const int k = S.cl_ans8 + 1;                                 /* the CU of this round (hv_cl_send_nxn counts it after the phase) */
+    const unsigned long long *tag = (const unsigned long long *)&im.cluster->res[2 + (k & 1)].tag;
+    for (;;) {
+        const unsigned long long t = hv_ld_flag64(tag);
+        if ((((unsigned)t >> 8) & 0xffffff) == (unsigned)(k & 0xffffff)) {
+            hv_acquire_fence(S.cl_light);
+            S.pf.w = (int)((unsigned)t & 0xff); S.pf.cost = (int)(t >> 32); S.pf.k = k;
+            return;
+        }
+        if (hv_poll(&S.c70_done) >= 5 || hv_peek(&S.cl_fail)) return;
+        hv_spin_pause();
+    }
+}
 static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q);
 static HDN void hv_nxn_helper(int q, HvCu cu, int h);
 static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m, int ctu, int wr_on, int cl) {
@@ -2660,6 +2688,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     if (hv_uni(cl) == 2) {                                       /* cluster of 4: this CU's block jobs and candidates 0..69 are another workgroup's */
         if (wv == 5) hv_c70_rider(hv_c70_area(s0, 1), q);          /* FAST analysis only (cl == 2) */
         if (wv >= 1 && wv <= 3) hv_nxn_helper(q, c8, wv - 1);      /* the NxN chain's block trials, 16 modes each */
+        if (wv == 4) hv_cl_peek8(S, im, lane);                    /* the 8x8 workgroup's answer, noticed while the chain runs */
         if (wv == 6 && k16 == 0 && m == 0 && hv_uni(S.nxv_pend)) hv_verify_nxn(lane, 1);   /* the previous CTU's NxN winners, off the critical path */
         return;
     }
@@ -3049,16 +3078,19 @@ static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu
     const int tid = hv_tid();
     HvLds::Level &L = S.lv[0];
     const int k = hv_uni(S.cl_ans8), slot = 2 + (k & 1);         /* this CU's number (hv_cl_send_nxn) */
+    const int pf = hv_uni(S.pf.k) == k;                          /* seen during the jobs phase (hv_cl_peek8; barriers since) */
     HV_PROFC(S, -1);
-    if (tid == 0) {
-        const unsigned long long to = (im.flags & 4) ? 100000ull : HV_CL_TIMEOUT;   /* test hook, see hv_cl_receive */
-        if (!hv_cl_wait(&im.cluster->res[slot].seq, k, &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
-        HV_PROFC(S, 0);
+    if (!pf) {
+        if (tid == 0) {
+            const unsigned long long to = (im.flags & 4) ? 100000ull : HV_CL_TIMEOUT;   /* test hook, see hv_cl_receive */
+            if (!hv_cl_wait(&im.cluster->res[slot].seq, k, &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
+        }
+        BLOCK_SYNC();
     }
-    BLOCK_SYNC();
+    HV_PROFC(S, 0);
     const HevceRes *r = &im.cluster->res[slot];
-    const int wa = hv_min(hv_max(hv_ldc_i32(&r->winner), 0), 69);
-    const int win70 = L.tcost[70] <= hv_ldc_i32(&r->cost);
+    const int wa = pf ? hv_min(hv_uni(S.pf.w), 69) : hv_min(hv_max(hv_ldc_i32(&r->winner), 0), 69);
+    const int win70 = L.tcost[70] <= (pf ? hv_uni(S.pf.cost) : hv_ldc_i32(&r->cost));
     const int w = win70 ? 70 : wa;
     HV_GLOBAL u8 *scr = hv_worker8_scratch(im, k);
     HvGLev glev = (HvGLev)scr;
@@ -3188,7 +3220,11 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
         hv_publish_fence(S.cl_light);                            /* the answer, and the winner's levels / samples in the level scratch */
         BLOCK_SYNC();
         if (tid == 0) {
-            if (cu.lvl == 0) { S.cl_ans8 = k8; hv_st_flag(&r->seq, k8); }
+            if (cu.lvl == 0) {
+                S.cl_ans8 = k8;
+                hv_st_flag64((unsigned long long *)&r->tag, ((unsigned long long)(unsigned)L.tcost[w] << 32) | ((unsigned)(k8 & 0xffffff) << 8) | (unsigned)w);
+                hv_st_flag(&r->seq, k8);
+            }
             else { const int sq = S.cl_seq[HV_CL_BOX(cu.lvl)] + 1; S.cl_seq[HV_CL_BOX(cu.lvl)] = sq; hv_st_flag(&r->seq, sq); }
         }
     }
@@ -3397,7 +3433,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int force_exact = (im.flags & 1) || !im.payload;      /* without the writer nothing vouches for the FAST decisions */
     const int pk_nxn = (im.flags >> 8) & 0xff, pk_wr = (im.flags >> 16) & 0xff;
     hv_set_mode(S, force_exact, tid);
-    if (tid == 0) { S.poison = 0; S.nxv_pend = 0; S.poison_prev = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_ans8 = 0; S.cl_fail = 0; S.cl_light = 0; S.cl_ok = 0; }
+    if (tid == 0) { S.poison = 0; S.nxv_pend = 0; S.poison_prev = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_ans8 = 0; S.pf.k = 0; S.cl_fail = 0; S.cl_light = 0; S.cl_ok = 0; }
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
     BLOCK_SYNC();
