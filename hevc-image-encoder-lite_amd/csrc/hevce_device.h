@@ -2632,7 +2632,7 @@ static HDN void hv_wr_engine(const HevceImageDesc &im_, int cw, int budget) {
    is through. */
 static HD void hv_cl_peek8(HvLds &S, const HevceImageDesc &im, int lane) {
     if (lane) return;
-    const int k = S.cl_ans8 + 1;                                 /* the CU of this round (hv_cl_send_nxn counts it after the phase) */
+    const int k = S.cl_ans8 + 1;                                 /* the CU of this round (its decision counts it) */
     const unsigned long long *tag = (const unsigned long long *)&im.cluster->res[2 + (k & 1)].tag;
     for (;;) {
         const unsigned long long t = hv_ld_flag64(tag);
@@ -2645,7 +2645,8 @@ static HD void hv_cl_peek8(HvLds &S, const HevceImageDesc &im, int lane) {
         hv_spin_pause();
     }
 }
-static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q);
+static HD void hv_cl_report_nxn(HvLds &S, const HevceImageDesc &im, int lane);
+static HDN void hv_c70_rider(const HevceImageDesc &im, HV_GLOBAL u16 *c70, int q);
 static HDN void hv_nxn_helper(int q, HvCu cu, int h);
 static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m, int ctu, int wr_on, int cl) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
@@ -2686,7 +2687,7 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         return;
     }
     if (hv_uni(cl) == 2) {                                       /* cluster of 4: this CU's block jobs and candidates 0..69 are another workgroup's */
-        if (wv == 5) hv_c70_rider(hv_c70_area(s0, 1), q);          /* FAST analysis only (cl == 2) */
+        if (wv == 5) hv_c70_rider(im, hv_c70_area(s0, 1), q);      /* FAST analysis only (cl == 2); it also reports the candidate to the 8x8 workgroup */
         if (wv >= 1 && wv <= 3) hv_nxn_helper(q, c8, wv - 1);      /* the NxN chain's block trials, 16 modes each */
         if (wv == 4) hv_cl_peek8(S, im, lane);                    /* the 8x8 workgroup's answer, noticed while the chain runs */
         if (wv == 6 && k16 == 0 && m == 0 && hv_uni(S.nxv_pend)) hv_verify_nxn(lane, 1);   /* the previous CTU's NxN winners, off the critical path */
@@ -2757,7 +2758,8 @@ static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu
 static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, int ctu, HevceRecord *rec, int32_t *dump, int cl) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, n = cu.n;
     HvLds::Level &L = S.lv[cu.lvl];
-    HV_GLOBAL u8 *scr = (n == 8 && cl == 2) ? hv_worker8_scratch(im, hv_uni(S.cl_ans8)) : hv_level_scratch(im, cu.lvl);   /* cl_ans8: this CU's number (hv_cl_send_nxn) */
+    const int k8 = hv_uni(S.cl_ans8) + 1;                        /* cluster of four: the number of this 8x8 CU since the launch; counted at the end of its decision */
+    HV_GLOBAL u8 *scr = (n == 8 && cl == 2) ? hv_worker8_scratch(im, k8) : hv_level_scratch(im, cu.lvl);
     HvGLev glev = (HvGLev)scr;
     HvGRec grec = (HvGRec)(scr + HV_TL * 1024 * 2);
     const int ntrials = (n == 8) ? 71 : 70;
@@ -2868,7 +2870,7 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
     }
     BLOCK_SYNC();
     HV_PROF(S, cu.lvl, 4);
-    if (n == 8 && cl == 2) HV_PROFC(S, 3);
+    if (n == 8 && cl == 2) { HV_PROFC(S, 3); if (tid == 0) S.cl_ans8 = k8; }   /* read again only behind the next barrier */
 }
 
 /* --------------------------------------------------------------------------------------------- */
@@ -2945,7 +2947,7 @@ static HD void hv_snapshot(HvLds &S, int lvl, int tid) {
    bins do not move the range: so SIXTEEN lanes code the candidate at once, one per flag pattern, block by block as the chain
    delivers the winners' tokens (the tokens are the same in every lane), and when the chain has fixed the modes the lane of the
    pattern that came true IS candidate 70.  Only the last block's tokens are left to code when the chain ends. */
-static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q) {
+static HDN void hv_c70_rider(const HevceImageDesc &im, HV_GLOBAL u16 *c70, int q) {
     HvLds &S = HV_S;
     HvLds::Level &L = S.lv[0];
     const int lane = hv_tid() & 63, pl = lane & 15, act = lane < 16;
@@ -2984,6 +2986,8 @@ static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q) {
         L.tdead[70] = 0; L.tpos[70] = -1;
     }
     for (int r = lane; r < HEVCE_NCTXP; r += 64) L.tctx[r][70] = L.tctx[r][pat];
+    WAVE_SYNC();
+    hv_cl_report_nxn(S, im, lane);
 }
 
 /* --------------------------------------------------------------------------------------------- */
@@ -2994,7 +2998,7 @@ static HDN void hv_c70_rider(HV_GLOBAL u16 *c70, int q) {
 /* chain does until the CU's decision, four (sixteen) rounds later.  Back comes the best unsplit candidate; the chain compares it  */
 /* with the split alternative and commits.  Clusters of four: a fourth workgroup evaluates candidates 0..69 of the 8x8 CUs too     */
 /* (the chain keeps the NxN candidate, number 70).  It is on the critical path, so it gets ONE message per 16x16 quad and walks    */
-/* the quad's four CUs on its own: after its answer for a CU it takes the chain's report of the NxN candidate (hv_cl_send_nxn),     */
+/* the quad's four CUs on its own: after its answer for a CU it takes the chain's report of the NxN candidate (hv_cl_report_nxn),   */
 /* makes the CU's decision itself -- the chain makes the same one from the same numbers -- and enters the next CU with the winner's */
 /* samples, modes, coder and contexts (hv_pw_advance8) while the chain is still committing.  Answers, reports and the 8x8          */
 /* candidates' trial scratch are double-buffered by the parity of the CU's number, so neither side can overwrite what the other     */
@@ -3025,30 +3029,31 @@ static HD void hv_cl_send(HvLds &S, const HevceImageDesc &im, const HvCu cu, int
     BLOCK_SYNC();
     if (tid == 0) { const int s = S.cl_seq[b] + 1; S.cl_seq[b] = s; hv_st_flag(&m->seq, s); }
 }
-/* chain workgroup, cluster of four, after an 8x8 CU's jobs phase: the NxN candidate is complete (its rider has coded it) -- report it
-   to the 8x8 workgroup, which then knows the CU's decision as soon as it has its own best candidate and goes on to the quad's next
-   CU without waiting for this workgroup's commit.  All threads. */
-static HD void hv_cl_send_nxn(HvLds &S, const HevceImageDesc &im) {
-    const int tid = hv_tid(), k = S.cl_ans8 + 1;
+/* chain workgroup, cluster of four: the NxN candidate is complete -- its rider (hv_c70_rider) has just coded it.  The rider's own
+   wavefront reports it to the 8x8 workgroup, which then knows the CU's decision as soon as it has its own best candidate and goes on
+   to the quad's next CU without waiting for this workgroup's commit.  One wavefront, inside the jobs phase: no barrier, and nothing
+   of it left between two jobs phases. */
+static HD void hv_cl_report_nxn(HvLds &S, const HevceImageDesc &im, int lane) {
+    const int k = hv_uni(S.cl_ans8) + 1;                         /* the CU of this round (its decision counts it) */
     HevceNxn *r = &im.cluster->nxn[k & 1];
     const HvLds::Level &L = S.lv[0];
-    if (tid == 0) {
+    if (lane == 0) {
         r->cost = L.tdead[70] ? HV_I32MAX : L.tcost[70]; r->range = L.tregs[70].range; r->nbits = L.tregs[70].nbits - L.tnlog[70];
         r->modes = S.nxn_modes[0] | (S.nxn_modes[1] << 8) | (S.nxn_modes[2] << 16) | (S.nxn_modes[3] << 24);
     }
-    if (tid < HEVCE_NCTXP) r->ctx[tid] = L.tctx[tid][70];
-    if (tid >= 128 && tid < 192) r->rec[tid - 128] = S.nxn_crec[(tid - 128) >> 3][(tid - 128) & 7];
+    for (int i = lane; i < HEVCE_NCTXP; i += 64) r->ctx[i] = L.tctx[i][70];
+    r->rec[lane] = S.nxn_crec[lane >> 3][lane & 7];
     hv_publish_fence(S.cl_light);
-    BLOCK_SYNC();
-    if (tid == 0) { S.cl_ans8 = k; hv_st_flag(&r->seq, k); }
+    WAVE_SYNC();
+    if (lane == 0) hv_st_flag(&r->seq, k);
 }
 /* chain workgroup, at the CU's decision: wait for the answer and make its candidate the only one alive of the level.  All threads. */
 static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu) {
     const int tid = hv_tid(), b = HV_CL_BOX(cu.lvl);
     HvLds::Level &L = S.lv[cu.lvl];
     const int size = im.cluster->size;
-    /* the answer to 8x8 CU number k (hv_cl_send_nxn counted it) is in res[2 + (k & 1)] */
-    const int want = cu.lvl == 0 ? hv_uni(S.cl_ans8) : hv_uni(S.cl_seq[b]), slot = cu.lvl == 0 ? 2 + (want & 1) : b;
+    /* the answer to 8x8 CU number k = cl_ans8 + 1 is in res[2 + (k & 1)] */
+    const int want = cu.lvl == 0 ? hv_uni(S.cl_ans8) + 1 : hv_uni(S.cl_seq[b]), slot = cu.lvl == 0 ? 2 + (want & 1) : b;
     if (tid == 0) {
         const unsigned long long to = (im.flags & 4) ? 100000ull : HV_CL_TIMEOUT;   /* test hook (flag bit 2): the workers have left, give up after 1 ms */
         if (!hv_cl_wait(&im.cluster->res[slot].seq, want, &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
@@ -3077,7 +3082,7 @@ static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu) 
 static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu cu, HevceRecord *rec) {
     const int tid = hv_tid();
     HvLds::Level &L = S.lv[0];
-    const int k = hv_uni(S.cl_ans8), slot = 2 + (k & 1);         /* this CU's number (hv_cl_send_nxn) */
+    const int k = hv_uni(S.cl_ans8) + 1, slot = 2 + (k & 1);     /* this CU's number; counted below */
     const int pf = hv_uni(S.pf.k) == k;                          /* seen during the jobs phase (hv_cl_peek8; barriers since) */
     HV_PROFC(S, -1);
     if (!pf) {
@@ -3128,6 +3133,7 @@ static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu
     }
     BLOCK_SYNC();
     HV_PROFC(S, 3);
+    if (tid == 0) S.cl_ans8 = k;                                 /* read again only behind the next barrier (the next round's jobs phase) */
 }
 /* the samples of a CU that has just been decided go to the picture's reconstruction at once (the parents of the NEXT CUs read them there) */
 static HD void hv_cl_store_rcon(HvLds &S, const HevceImageDesc &im, const HvCu cu, int y0, int x0) {
@@ -3543,7 +3549,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                         if (k == 1 && m == 2) hv_level_contexts(S, im, c32);     /* its jobs ran in five phases up to this one */
                     }
                     if (!cl8) hv_engine_phase(S, im, cl ? 1 : (1 | (m >= 1 ? 2 : 0) | ((k >= 2 || (k == 1 && m == 3)) ? 4 : 0)), 0);   /* cluster of 4: candidate 70 has been coded by its rider */
-                    else { HV_PROFC(S, -1); hv_cl_send_nxn(S, im); HV_PROFC(S, 1); }   /* ... and the 8x8 workgroup may know it now */
+                    else { HV_PROFC(S, -1); HV_PROFC(S, 1); }     /* ... who has also reported it to the 8x8 workgroup */
                 }
                 hv_decide_cu(S, im, cu, ctu, rec, im.dump ? im.dump + ((size_t)ctu * 21 + step) * HV_TL * 16 : nullptr, cl + cl8);
                 if (cl && (cu.n == 16 || (cl8 && cu.n == 8))) hv_cl_store_rcon(S, im, cu, y0, x0);   /* the next CU's candidates elsewhere predict from these samples */
