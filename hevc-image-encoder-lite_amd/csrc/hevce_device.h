@@ -3283,7 +3283,7 @@ static HD int hv_pw_advance8(HvLds &S, const HevceImageDesc &im, const HvCu cu, 
     const int w = hv_min(hv_max(S.winner, 0), 69);
     const int win70 = hv_ldc_i32(&r->cost) <= L.tcost[w];
     HvGRec grec = (HvGRec)(hv_worker8_scratch(im, k) + HV_TL * 1024 * 2);
-    BLOCK_SYNC();                                                /* everyone has the decision before the entry state changes */
+    /* (what the decision reads -- the winner's cost, index -- is not what is written below: no barrier in between) */
     if (tid < 64) S.rec[cu.y + (tid >> 3) + 1][cu.x + (tid & 7) + HV_RX] = win70 ? (u8)hv_ldc_u8(&r->rec[tid]) : grec[w * 1024 + tid];
     if (tid >= 64 && tid < 68) {
         const int s = tid - 64, md = win70 ? (hv_ldc_i32(&r->modes) >> (8 * s)) & 0xff : (w < 35 ? w : w - 35);
@@ -3292,12 +3292,11 @@ static HD int hv_pw_advance8(HvLds &S, const HevceImageDesc &im, const HvCu cu, 
     if (tid == 128) { S.ent[0].range = win70 ? hv_ldc_i32(&r->range) : L.tregs[w].range; S.ent[0].nbits = win70 ? hv_ldc_i32(&r->nbits) : L.tregs[w].nbits - L.tnlog[w]; }
     if (tid >= 256 && tid < 256 + HEVCE_NCTXP) S.ent_ctx[0][tid - 256] = win70 ? (u8)hv_ldc_u8(&r->ctx[tid - 256]) : L.tctx[tid - 256][w];
     BLOCK_SYNC();
-    if (tid == 0) {                                              /* the next CU's neighbour modes  [ref :1369-1373] */
+    if (tid == 0) {                                              /* the next CU's neighbour modes  [ref :1369-1373]; read behind the next stage's first barrier */
         const int qy = 2 * ((m + 1) >> 1), qx = 2 * ((m + 1) & 1);
         L.ml = qx > 0 ? S.q8.pm[qy][qx - 1] : (qy == 0 ? S.q8.ml0 : S.q8.ml2);
         L.ma = qy > 0 ? S.q8.pm[qy - 1][qx] : (qx == 0 ? S.q8.ma0 : S.q8.ma2);
     }
-    BLOCK_SYNC();
     return 1;
 }
 /* The parent workgroup of a picture (cluster mode, second workgroup): it answers the chain workgroup's messages until told to
@@ -3363,6 +3362,7 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
 #endif
                 }
                 for (int st = 0; st < 3; st++) {
+                    if (b == 2 && st == 1) continue;             /* an 8x8 CU's stage 0 includes its binarisation and engines */
                     hv_pw_stage(S, im, cu, st, b == 2 ? lo8 : 0, b == 2 ? hi8 : 70, b == 2 ? slot8 : b);
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
                     if (tid == 0 && b == 2) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[2 + st] += n_ - wt_; wt_ = n_; }
