@@ -146,8 +146,13 @@ static HD unsigned hv_ldg_u32(const unsigned *p) { return __hip_atomic_load(p, _
 #define HV_PROF2_T0() unsigned long long p2_ = __builtin_amdgcn_s_memtime()
 /* chain workgroup, cluster of four: the section between two 8x8 jobs phases, piece i into prof2[5 + i] (i < 0: only restart the clock) */
 #define HV_PROFC(S, i) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if ((i) >= 0) (S).prof2[5 + (i)] += n_ - (S).prof_pt; (S).prof_pt = n_; } } while (0)
+#ifdef HEVCE_PROF_LIGHT                                      /* only the stamps between two jobs phases and the 8x8 workgroup's waits: close to the product's timing */
+#define HV_PROF2(S, ph) do { (void)p2_; } while (0)
+#define HV_PROF(S, lvl, ph) do { (void)pt_; } while (0)
+#else
 #define HV_PROF2(S, ph) do { if ((hv_tid() & 63) == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof2[ph] += n_ - p2_; p2_ = n_; } } while (0)
 #define HV_PROF(S, lvl, ph) do { if (hv_tid() == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (S).prof[lvl][ph] += n_ - pt_; pt_ = n_; } } while (0)
+#endif
 #else
 #define HV_PROF_T0() do { } while (0)
 #define HV_PROF2_T0() do { } while (0)
@@ -3163,7 +3168,7 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
             hv_level_contexts(S, im, cu);                        /* ends with a barrier */
             const int nchain = hi > 35 ? 3 : 0;
             int tb = -1, tc = 0;
-#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+#if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
             unsigned long long w8_ = __builtin_amdgcn_s_memtime();
 #define HV_W8T(i) do { if (lane == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[8 + 3 * wv + (i)] += n_ - w8_; w8_ = n_; } } while (0)
 #else
