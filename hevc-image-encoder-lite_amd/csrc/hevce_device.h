@@ -252,7 +252,7 @@ struct alignas(16) HvLds {
     /* candidates ("trials") of the CU under evaluation at each level: 0 = 8x8, 1 = 16x16, 2 = 32x32.  A parent's
        candidates are prepared at ITS entry and their arithmetic engines advance in slices during the children's phases. */
     struct Level {
-        u8  tctx[HEVCE_NCTXP][HV_TL];                       /* context bytes, one column per candidate */
+        alignas(4) u8 tctx[HEVCE_NCTXP][HV_TL];                     /* context bytes, one column per candidate */
         HevceCoderRegs tregs[HV_TL];
         int tcost[HV_TL], tsse[HV_TL];
         int tlen[HV_TL], tpos[HV_TL];                       /* list entries; position (entry | chunk << 8), -1 = finished / abandoned */
@@ -2232,7 +2232,8 @@ static HD void hv_level_contexts(HvLds &S, const HevceImageDesc &im, const HvCu 
     const int tid = hv_tid();
     HvLds::Level &L = S.lv[cu.lvl];
     HV_PROF_T0();
-    for (int k = tid; k < HEVCE_NCTXP * HV_TL; k += HV_NTHREADS) L.tctx[k / HV_TL][k % HV_TL] = S.ent_ctx[cu.lvl][k / HV_TL];
+    /* a row of the context columns is HV_TL = 72 bytes = 18 dwords of the same byte */
+    for (int j = tid; j < HEVCE_NCTXP * HV_TL / 4; j += HV_NTHREADS) ((HV_LDSP unsigned *)&L.tctx[0][0])[j] = (unsigned)S.ent_ctx[cu.lvl][j / (HV_TL / 4)] * 0x01010101u;
     if (tid < 70) L.tregs[tid] = S.ent[cu.lvl];
     BLOCK_SYNC();
     HV_PROF(S, cu.lvl, 5);
@@ -3203,27 +3204,23 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
     } else {
         /* four engine wavefronts, one per SIMD (18 candidates each): the loop is one dependent instruction stream, two of them on a
            SIMD take turns (measured: 8 x 9 lanes 44.8 k cycles per 8x8 CU, 4 x 18 lanes less) */
-        if (cu.n != 8) hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, 1 << cu.lvl, nullptr, 4, wave < 4 ? wave : -1);
-        BLOCK_SYNC();
-        if (wv == 0) {                                           /* arg-min, the later candidate wins ties  [ref :1440, 1476] */
-            int bc = HV_I32MAX, bi = -2;
+        if (cu.n != 8) { hv_run_engines((HV_GLOBAL u8 *)im.scratch, q, 1 << cu.lvl, nullptr, 4, wave < 4 ? wave : -1); BLOCK_SYNC(); }   /* (8x8: stage 0 ended with a barrier) */
+        int bc = HV_I32MAX, bi = -2;                             /* arg-min, the later candidate wins ties  [ref :1440, 1476]: every wavefront for itself (an all-reduce), no barrier */
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int t = lane + 64 * u;
-                const bool ok = t < 70 && !L.tdead[hv_min(t, HV_TL - 1)];
-                const int c = L.tcost[hv_min(t, HV_TL - 1)];
-                const bool take = ok && (bi == -2 || c < bc || (c == bc && t > bi));
-                bc = take ? c : bc; bi = take ? t : bi;
-            }
-            for (int sft = 1; sft < 64; sft <<= 1) {
-                const int oc = hv_shfl_xor(bc, sft), oi = hv_shfl_xor(bi, sft);
-                const bool take = oi != -2 && (bi == -2 || oc < bc || (oc == bc && oi > bi));
-                bc = take ? oc : bc; bi = take ? oi : bi;
-            }
-            if (lane == 0) S.winner = bi;
+        for (int u = 0; u < 2; u++) {
+            const int t = lane + 64 * u;
+            const bool ok = t < 70 && !L.tdead[hv_min(t, HV_TL - 1)];
+            const int c = L.tcost[hv_min(t, HV_TL - 1)];
+            const bool take = ok && (bi == -2 || c < bc || (c == bc && t > bi));
+            bc = take ? c : bc; bi = take ? t : bi;
         }
-        BLOCK_SYNC();
-        const int w = hv_min(hv_max(S.winner, 0), 69);
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int oc = hv_shfl_xor(bc, sft), oi = hv_shfl_xor(bi, sft);
+            const bool take = oi != -2 && (bi == -2 || oc < bc || (oc == bc && oi > bi));
+            bc = take ? oc : bc; bi = take ? oi : bi;
+        }
+        if (tid == 0) S.winner = bi;                             /* for hv_pw_advance8, behind the barrier below */
+        const int w = hv_min(hv_max(hv_bcast0(bi), 0), 69);
         const int k8 = hv_uni(S.cl_ans8) + 1;                     /* 8x8: this is the answer to CU number k8 of the launch */
         HevceRes *r = &im.cluster->res[cu.lvl == 0 ? 2 + (k8 & 1) : slot];
         if (tid == 0) { r->cost = L.tcost[w]; r->winner = w; r->sse = L.tsse[w]; r->range = L.tregs[w].range; r->nbits = L.tregs[w].nbits - L.tnlog[w]; r->pad_[0] = S.cl_light ? 1 : 2; }
