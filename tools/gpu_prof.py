@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """In-kernel cycle probes (probe builds of the library: `make -C hevc-image-encoder-lite_amd/csrc prof prof2 wait bin jdur-N tu-N`).
 
-  gpu_prof.py phases [h w]   per-phase cycles per CU size                          (libhevce_prof.so,  -DHEVCE_PROF)
+  gpu_prof.py phases [h w]   per-phase cycles per CU size; clusters of four: the 8x8 workgroup's wavefronts and the chain workgroup's
+                             section between two jobs phases                        (libhevce_prof.so,  -DHEVCE_PROF)
+                             HEVCE_LIB=.../libhevce_light.so (make light): only the hand-off stamps, near-product timing
   gpu_prof.py nxn            inside the NxN chain's 4x4 stages                     (libhevce_prof2.so, + -DHEVCE_PROF_NXN)
   gpu_prof.py wait           wavefront 0's wait at the barrier closing each round  (libhevce_wait.so,  + -DHEVCE_PROF_WAIT)
   gpu_prof.py bin            binarisation passes per CU level                      (libhevce_bin.so,   + -DHEVCE_PROF_BIN)
