@@ -75,6 +75,6 @@ elif kind == "bin":
 elif kind == "tu":
     N = int(arg)
     v6 = p2[16:22]
-    calls = {32: 18, 16: 36 + 9 * 4, 8: 80 + 20 * 4}[N] * nctu
+    calls = {32: 18, 16: 36 + 9 * 4, 8: 80 + 20 * 4, 4: 16 * 3 * 4}[N] * nctu     # 4: the TU-split chains of the 8x8 CUs, three wavefronts x four blocks
     print(f"hv_tu_job<{N}>: {v6.sum()/calls/1e3:.1f} k cycles per call")
     for nm, v in zip(("refs", "predict", "fwd cols", "fwd rows+quant", "inv cols", "inv rows+recon"), v6): print(f"  {nm:16s} {v/calls/1e3:7.1f} k  {100*v/v6.sum():5.1f}%")
