@@ -1245,7 +1245,7 @@ static HD HvTuOut hv_tu_job(int wave, int lane, int q,
         braw[1 + 2 * N + j] = (u8)a0; braw[1 + 3 * N + j] = (u8)a1;
     }
     WAVE_SYNC();
-    {
+    if constexpr (N > 4) {                                       /* 4x4 blocks never read the smoothed samples (hv_smoothed) */
         const u8 *l = braw + 1, *a = braw + 1 + 2 * N;
         const int c = braw[0];
         if (j == 0) {

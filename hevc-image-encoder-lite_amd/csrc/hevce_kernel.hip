@@ -25,14 +25,10 @@ extern "C" int hevce_launch_analyse(const HevceImageDesc *d_images, int n, int c
 }
 
 /* ---- function-level test hook: the TU pipeline (prediction -> T -> Q -> Q^-1 -> T^-1 -> reconstruction) for all 35
-   modes of ONE n x n block at the CTU origin, from an explicit 33x65 neighbourhood.  One wavefront. ------------------- */
-extern "C" __global__ void __launch_bounds__(64, 1)
-hevce_test_tu_kernel(const unsigned char *org /*32x32*/, const unsigned char *nbr /*33x65: row 0 = y-1, col 0 = x-1*/,
-                     int n, int q, int aL, int aLB, int aA, int aAR,
-                     short *lev /*35 x 1024, scan order*/, unsigned char *rec /*35 x 1024*/, int *info /*35 x 4: sse,last,cbf,cgsig_lo*/,
-                     const unsigned short *qlut) {
-    HvLds &S = HV_S;
-    const int tid = (int)threadIdx.x;
+   modes of ONE N x N block at the CTU origin, from an explicit 33x65 neighbourhood.  One wavefront.  One kernel per block size:
+   all four instantiations of hv_tu_job inlined into one kernel needed 342 registers, and the allocator's VGPR -> AGPR spill copies
+   ended up in front of an EXEC restore (tools/isa_lint.py, experiments/README.md round 3). ------------------- */
+static __device__ void hv_test_init(HvLds &S, const unsigned char *org, const unsigned char *nbr, int q, const unsigned short *qlut, int tid) {
     hv_init_tables(S, q, tid);
     for (int p = tid; p < 1024; p += 64) S.org[p >> 5][p & 31] = org[p];
     for (int p = tid; p < 33 * 65; p += 64) S.rec[p / 65][HV_RX - 1 + p % 65] = nbr[p];
@@ -52,24 +48,33 @@ hevce_test_tu_kernel(const unsigned char *org /*32x32*/, const unsigned char *nb
         }
     }
     __syncthreads();
-    const int per = 64 / n;
+}
+template <int N> __global__ void __launch_bounds__(64, 1)
+hevce_test_tu_kernel(const unsigned char *org /*32x32*/, const unsigned char *nbr /*33x65: row 0 = y-1, col 0 = x-1*/,
+                     int q, int aL, int aLB, int aA, int aAR,
+                     short *lev /*35 x 1024, scan order*/, unsigned char *rec /*35 x 1024*/, int *info /*35 x 4: sse,last,cbf,cgsig_lo*/,
+                     const unsigned short *qlut) {
+    HvLds &S = HV_S;
+    const int tid = (int)threadIdx.x;
+    hv_test_init(S, org, nbr, q, qlut, tid);
+    constexpr int per = 64 / N;
     for (int grp = 0; grp * per < HEVCE_NMODES; grp++) {
-        const int mode = grp * per + tid / n;
+        const int mode = grp * per + tid / N;
         const bool ok = mode < HEVCE_NMODES;
-        HvTuOut o;
         HvGLev ld = (HvGLev)(lev + (ok ? mode : 0) * 1024);
         HvGRec rd = (HvGRec)(rec + (ok ? mode : 0) * 1024);
-        if (n == 4)       o = hv_tu_job<4, HvGLev, HvGRec>(0, tid, q, 0, 0, 0, 0, n, nullptr, 0, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
-        else if (n == 8)  o = hv_tu_job<8, HvGLev, HvGRec>(0, tid, q, 0, 0, 0, 0, n, nullptr, 0, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
-        else if (n == 16) o = hv_tu_job<16, HvGLev, HvGRec>(0, tid, q, 0, 0, 0, 0, n, nullptr, 0, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
-        else              o = hv_tu_job<32, HvGLev, HvGRec>(0, tid, q, 0, 0, 0, 0, n, nullptr, 0, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, n);
-        if (ok && tid % n == 0) { info[mode * 4] = o.sse; info[mode * 4 + 1] = o.last; info[mode * 4 + 2] = o.cbf; info[mode * 4 + 3] = (int)(o.cgsig & 0xffffffffu); }
+        const HvTuOut o = hv_tu_job<N, HvGLev, HvGRec>(0, tid, q, 0, 0, 0, 0, N, nullptr, 0, aL, aLB, aA, aAR, ok ? mode : -1, ld, rd, N);
+        if (ok && tid % N == 0) { info[mode * 4] = o.sse; info[mode * 4 + 1] = o.last; info[mode * 4 + 2] = o.cbf; info[mode * 4 + 3] = (int)(o.cgsig & 0xffffffffu); }
     }
 }
 
 extern "C" int hevce_launch_test_tu(const unsigned char *org, const unsigned char *nbr, int n, int q, int aL, int aLB, int aA, int aAR,
                                     short *lev, unsigned char *rec, int *info, const unsigned short *qlut, hipStream_t stream) {
-    hipLaunchKernelGGL(hevce_test_tu_kernel, dim3(1), dim3(64), 0, stream, org, nbr, n, q, aL, aLB, aA, aAR, lev, rec, info, qlut);
+    if (n == 4)       hipLaunchKernelGGL(hevce_test_tu_kernel<4>, dim3(1), dim3(64), 0, stream, org, nbr, q, aL, aLB, aA, aAR, lev, rec, info, qlut);
+    else if (n == 8)  hipLaunchKernelGGL(hevce_test_tu_kernel<8>, dim3(1), dim3(64), 0, stream, org, nbr, q, aL, aLB, aA, aAR, lev, rec, info, qlut);
+    else if (n == 16) hipLaunchKernelGGL(hevce_test_tu_kernel<16>, dim3(1), dim3(64), 0, stream, org, nbr, q, aL, aLB, aA, aAR, lev, rec, info, qlut);
+    else if (n == 32) hipLaunchKernelGGL(hevce_test_tu_kernel<32>, dim3(1), dim3(64), 0, stream, org, nbr, q, aL, aLB, aA, aAR, lev, rec, info, qlut);
+    else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -80,23 +85,7 @@ hevce_test_chain_kernel(const unsigned char *org, const unsigned char *nbr, int 
                         unsigned char *scratch /*HEVCE_SCRATCH_BYTES*/, int *info /*35 x 16*/, const unsigned short *qlut) {
     HvLds &S = HV_S;
     const int tid = (int)threadIdx.x;
-    hv_init_tables(S, q, tid);
-    for (int p = tid; p < 1024; p += 64) S.org[p >> 5][p & 31] = org[p];
-    for (int p = tid; p < 33 * 65; p += 64) S.rec[p / 65][HV_RX - 1 + p % 65] = nbr[p];
-    if (tid < 35) { S.ang[tid] = hv_ang[tid]; S.invang[tid] = hv_invang[tid]; }   /* no thread 384 in a single-wave block */
-    if (tid == 0) {
-        S.trace = nullptr; S.qlut = qlut;
-        int k = 0;
-        for (int d = 0; d <= 6; d++)
-            for (int y = (d < 4 ? d : 3); y >= 0 && d - y < 4; y--) { S.d4pos[k] = (u8)((y << 2) | (d - y)); S.d4idx[(y << 2) | (d - y)] = (u8)k; k++; }
-        for (int t = 0; t < 3; t++) {
-            const int ng = 2 << t;
-            k = 0;
-            for (int d = 0; d <= 2 * (ng - 1); d++)
-                for (int y = (d < ng ? d : ng - 1); y >= 0 && d - y < ng; y--) { S.cgpos[t][k] = (u8)((y << 3) | (d - y)); S.cgidx[t][y * ng + (d - y)] = (u8)k; k++; }
-        }
-    }
-    __syncthreads();
+    hv_test_init(S, org, nbr, q, qlut, tid);
     HvGLev glev = (HvGLev)scratch;
     HvGRec grec = (HvGRec)(scratch + HV_TL * 1024 * 2);
     HvCu cu = { 0, 0, n, n == 8 ? 3 : n == 16 ? 4 : 5, n == 8 ? 0 : n == 16 ? 1 : 2, aL, aLB, aA, aAR };
