@@ -41,6 +41,16 @@ static inline unsigned hv_perm(unsigned a, unsigned b, unsigned sel) {
     return r;
 }
 static inline void hv_atomic_add(int *p, int v) { *p += v; }
+static inline int hv_shfl(int v, int src) {
+    const int w = emu_cur >> 6, l = emu_cur & 63;
+    emu_stage[w][l] = v;
+    emu_wave_sync();
+    const int r = emu_stage[w][src & 63];
+    emu_wave_sync();
+    return r;
+}
+template <int S_> static inline int hv_row_get(int v) { const int l = emu_cur & 63; return hv_shfl(v, (l & ~15) | ((l + S_) & 15)); }
+template <int K_> static inline int hv_quad_get(int v) { const int l = emu_cur & 63; return hv_shfl(v, (l & ~3) | K_); }
 struct HvLaneTab { int a[64]; };                            /* emulation: the one fiber that runs wave-uniform code owns all 64 entries */
 #define HV_LT_LOAD(tab, L, expr) do { for (int L = 0; L < 64; L++) (tab).a[L] = (expr); } while (0)
 #define HV_LT_EACH(tab, L, VAL, stmt) do { for (int L = 0; L < 64; L++) { const int VAL = (tab).a[L]; stmt; } } while (0)
@@ -92,6 +102,11 @@ static HD unsigned long long hv_ballot(int p) { return __ballot(p); }   /* one b
 static HD int  hv_clzll(unsigned long long v) { return __clzll((long long)v); }
 static HD unsigned hv_perm(unsigned a, unsigned b, unsigned sel) { return __builtin_amdgcn_perm(a, b, sel); }   /* v_perm_b32: result byte i = byte sel.byte[i] of {a:7..4, b:3..0} */
 static HD void hv_atomic_add(int *p, int v) { atomicAdd(p, v); }
+/* data-parallel primitives (DPP: the operand comes from another lane of the same row of 16 / quad of 4, no LDS involved):
+   hv_row_get<s>(v): v of lane (l & ~15) | ((l + s) & 15)   [row_ror:16-s]      hv_quad_get<k>(v): v of lane (l & ~3) | k   [quad_perm] */
+template <int S_> static HD int hv_row_get(int v) { return (S_ & 15) ? __builtin_amdgcn_update_dpp(0, v, 0x120 + ((16 - S_) & 15), 0xf, 0xf, false) : v; }
+template <int K_> static HD int hv_quad_get(int v) { return __builtin_amdgcn_update_dpp(0, v, K_ * 0x55, 0xf, 0xf, false); }
+static HD int hv_shfl(int v, int src) { return __shfl(v, src, 64); }                 /* any lane (ds_bpermute) */
 /* a 64-entry table with entry i in lane i of one VGPR: read / written with a wave-uniform index by v_readlane / v_writelane,
    i.e. without any memory access, and the result is wave-uniform (scalar arithmetic from there on) */
 struct HvLaneTab { int v; };
@@ -219,6 +234,21 @@ DEVCONST u8 hv_sigpos[8]   = HEVCE_TAB_SIGPOS;
 /* LDS image                                                                                       */
 /* --------------------------------------------------------------------------------------------- */
 struct HvTuInfo { u64 cgsig; int last; int cbf; };          /* per (trial, TU): 8x8 bitmap of non-zero 4x4 groups */
+/* HvLds::ftab -- what a context byte of the FRESH set becomes after a short string of bins (the NxN sub-search codes every 4x4
+   block trial from fresh contexts, and no context of a 4x4 block sees more than a few bins): [0, NCTXP) the fresh bytes themselves;
+   SIG: sig_coeff_flag class c after the bins idx = 1 << k | bits (k <= 2 earlier flags of the class, the first one bit 0);
+   ONE3: greater1 context 3 after k zeros; ONE0: greater1 context 0 after idx = 1 << k | bits (k <= 6, the first one bit 0) */
+#define HV_FT_SIG   HEVCE_NCTXP
+#define HV_FT_ONE3  (HV_FT_SIG + 9 * 8)
+#define HV_FT_ONE0  (HV_FT_ONE3 + 8)
+#define HV_FT_SIZE  (HV_FT_ONE0 + 128)
+/* FAST tables of the 4x4 block trials with one lane per sample (hv_tu4_px / hv_tok4_px), built by hv_set_mode */
+struct HvFx4 {
+    u16 sig4[3][16];                                        /* per scan kind and scan position: sig_coeff_flag context class | earlier positions of the class (HvSig4Info) */
+    u8  scan4[3][16];                                       /* per scan kind: raster position (y << 2 | x) -> scan position */
+    u8  unscan4[3][16];                                     /* ... and scan position -> raster position */
+    int d4[16];                                             /* the 4-point DST  [ref :391-396] */
+};
 
 struct alignas(16) HvWaveScr {                              /* private to one wavefront */
     short scr[64 * 34];                                     /* [slot][row][N+2]: transposition buffer           */
@@ -270,7 +300,10 @@ struct alignas(16) HvLds {
     alignas(16) short nxn_bestlev[4][16];
     alignas(16) u16 nxn_tok[35][144];                                 /* per candidate: its token stream (header + one group), 16-byte rows */
     u8    nxn_crec[8][8];
-    u8    nxn_line[35][16];                                 /* per mode: angular reference line r(-4..9) */
+    union {
+        u8    nxn_line[35][16];                             /* EXACT (one lane per mode): the mode's angular reference line r(-4..9) */
+        HvFx4 fx;                                           /* FAST (one lane per sample) */
+    };
     u8    nxn_bord[20];                                     /* raw reference samples of the current 4x4: corner, left[8], above[8] */
     int   nxn_modes[4];
     union {
@@ -279,11 +312,12 @@ struct alignas(16) HvLds {
             alignas(16) short nxv_lev[64][16];              /* levels in scan order */
             u16   nxv_info[64];                             /* last position | scan kind << 4 | has levels << 6 */
             short nxv_bits[64];                             /* the bit count the FAST engine gave it */
+            u8    ftab[HV_FT_SIZE];                         /* context bytes a FRESH context set passes through (hv_set_mode): the resolved tokens of the NxN sub-search */
         };
     };
     int   nxn_ntok[35];                                     /* per mode of the current 4x4 block: tokens | bypass bins << 8 | bits << 20 */
     int   c70_len, c70_byp;                                 /* tokens / bypass bins of candidate 70's stream so far */
-    int   nxq_mag, nxn_magn[35];                            /* cluster of four: stages whose greater / remainder tokens a helper has written (second half of the nxn_tok rows); per mode tokens | bypass bins << 8 */
+    int   c70_rd, nxn_magn[35];                             /* cluster of four: blocks candidate 70's rider has consumed; FAST, per mode of the current 4x4 block: tokens | bypass bins << 8 */
     int   nxq_go, nxq_done;                                 /* cluster of four: 4x4 blocks whose reference samples are laid out; helper wavefronts done, in all */
     int   c70_done, c70_seg[4], c70_pat;                    /* FAST: stages whose winner's tokens are in the stream (5: header known too); per stage offset | tokens << 16 | cbf << 31; the CU header's four prev_intra_luma_pred_flags */
     u8    nxn_ctx[HEVCE_NCTXP][HV_TL];                      /* context columns of the NxN chain's 35 modes (fresh per 4x4 block) */
@@ -354,12 +388,27 @@ static HD int hv_abs(int a) { return a < 0 ? -a : a; }
 static HD int hv_clip16(int v) { return hv_min(hv_max(v, -32768), 32767); }
 static HD int hv_clip8(int v) { return hv_min(hv_max(v, 0), 255); }
 
+/* context byte (state << 1 | mps) of context i at the start of a slice  [ref :727-735]; after one more bin  [ref :914-933] */
+static HD int hv_ctx_fresh_value(int i, int q) {
+    const int iv = hv_ctxinit[i], qp = 6 * q + 4;
+    int st = ((((iv >> 4) * 5 - 45) * qp) >> 4) + ((iv & 15) << 3) - 16;
+    st = hv_min(hv_max(st, 1), 126);
+    return st >= 64 ? (((st - 64) << 1) | 1) : ((63 - st) << 1);
+}
+static HD int hv_ctx_next(int cv, int bin) {
+    const int st = cv >> 1, mps = cv & 1;
+    if (bin != mps) return st == 0 ? (mps ^ 1) : ((hv_lpsnext[st] << 1) | mps);
+    return st < 62 ? cv + 2 : cv;
+}
+
 /* [ref HEVCe.c:177-185] */
 static HD int hv_rdcost(int q, int dist, int bits) {
     const int wd = (q < 3) ? 11 : (q == 3 ? 5 : 1);
     const int wb = (q == 0) ? 1 : (q == 1) ? 4 : (q == 2) ? 16 : (q == 3) ? 29 : 23;
-    const int a = (HV_I32MAX / wd <= dist) ? HV_I32MAX : wd * dist;
-    const int b = (HV_I32MAX / wb <= bits) ? HV_I32MAX : wb * bits;
+    const int gd = (q < 3) ? HV_I32MAX / 11 : (q == 3 ? HV_I32MAX / 5 : HV_I32MAX);                  /* I32MAX / weight: no division at run time */
+    const int gb = (q == 0) ? HV_I32MAX : (q == 1) ? HV_I32MAX / 4 : (q == 2) ? HV_I32MAX / 16 : (q == 3) ? HV_I32MAX / 29 : HV_I32MAX / 23;
+    const int a = (gd <= dist) ? HV_I32MAX : wd * dist;
+    const int b = (gb <= bits) ? HV_I32MAX : wb * bits;
     return (HV_I32MAX - a <= b) ? HV_I32MAX : a + b;
 }
 
@@ -1848,36 +1897,249 @@ static HD void hv_tu4_quad(HvLds &S, int q, int ty, int tx, int m, int ok) {
     }
     WAVE_SYNC();
 }
+/* --------------------------------------------------------------------------------------------- */
+/* FAST NxN sub-search with ONE LANE PER SAMPLE.                                                                               */
+/*                                                                                                                            */
+/* A wavefront issues one instruction per ~4.5 cycles however many lanes are active, so a phase costs its per-lane INSTRUCTION  */
+/* COUNT: with one lane per mode (hv_tu4_lane) a 4x4 block trial is ~1400 instructions, its binarisation ~800.  Here lane =     */
+/* (mode slot, sample): a wavefront tries FOUR modes per pass, a mode's sixteen samples are one DPP row -- the transforms are   */
+/* four multiply-adds with operands fetched from the row / the quad (no LDS, no barrier), sums are four rotations -- and the     */
+/* binarisation has one lane per scan position: non-zero masks are ballots, "how many before me" a popcount.  ~450 instructions  */
+/* per pass instead of ~2200 per mode.                                                                                         */
+/* The bins are written as RESOLVED tokens: in CABACputBin  [ref :914-933] the context byte evolves from `bin != mps` alone, and  */
+/* the trials of the sub-search all start from the FRESH context set  [ref :1505-1506], so the state a bin meets is a small       */
+/* table look-up on the bins of its context before it (S.ftab).  Token: bits 16.. = context byte << 1 | bin = the index of the    */
+/* engine's table entry (S.ctab2), bits 0..15 = the plain token for whoever codes the same bins from another state (candidate     */
+/* 70).  The engine (hv_rengine) then has no memory access on its dependency chain: perm -> sub -> select -> ffbh -> shift.       */
+/* --------------------------------------------------------------------------------------------- */
+#define HV_RTOK(cv, bin, plain) ((unsigned)(plain) | ((unsigned)(((cv) << 1) | (bin)) << 16))
+#define HV_RTOK_NOP (((unsigned)(HV_PADCV << 1) << 16) | HV_TOK_NOPF)
+/* FAST rows of S.nxn_tok (288 bytes): resolved tokens as 32-bit words from word 4 (<= 8 + 15 + 9 and 8 no-ops), 16-byte aligned for
+   the engine's chunk loads; from byte 224 the block's non-zero magnitudes in coding order, 16-bit */
+#define HV_NXR_TOK  4
+#define HV_NXR_COMP 112
+struct HvPx4 { int dcol[4], drow[4], tcol[4], trow[4]; };   /* this lane's transform coefficients (lane & 15 = y << 2 | x) */
+/* cluster of four: the chain workgroup has no 32x32 candidates of its own, so their slot lists (S.slist2) are free: behind the copy of
+   the NxN winners (hv_nxv_copy, 2.3 KB) sit the first 2048 entries of the picture's 4x4 level table (hv_fill_lut4; what a FAST
+   picture's EXACT CTU overwrites is laid out again when the workgroup goes back to FAST) */
+static HD const HV_LDSP u16 *hv_lut4_lds(const HvLds &S, int on) { return on ? (const HV_LDSP u16 *)((const HV_LDSP u8 *)&S.slist2[0][0] + 2560) : (const HV_LDSP u16 *)nullptr; }
+static HD void hv_fill_lut4(HvLds &S, int tid) {
+    HV_LDSP u16 *dst = (HV_LDSP u16 *)((HV_LDSP u8 *)&S.slist2[0][0] + 2560);
+    const HvQlut lut = hv_qlut<2>(S);
+    for (int i = tid; i < 2048; i += HV_NTHREADS) dst[i] = lut[i];
+}
+static HD void hv_px4_consts(const HvLds &S, HvPx4 &K, int lane) {
+    const int y = (lane >> 2) & 3, x = lane & 3;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        K.dcol[s] = S.fx.d4[y * 4 + ((y + s) & 3)];           /* forward, columns: row y of the result sums D[y][k] * r[k][x], k = (y + s) & 3 */
+        K.drow[s] = S.fx.d4[x * 4 + s];                     /* forward, rows   : coefficient (y, x) sums t[y][k] * D[x][k] */
+        K.tcol[s] = S.fx.d4[((y + s) & 3) * 4 + y];           /* inverse, columns: D[k][y] * r[k][x] */
+        K.trow[s] = S.fx.d4[s * 4 + x];                     /* inverse, rows   : t[y][k] * D[k][x] */
+    }
+}
+static HD int hv_row_sum(int v) { v += hv_row_get<8>(v); v += hv_row_get<4>(v); v += hv_row_get<2>(v); v += hv_row_get<1>(v); return v; }   /* over the 16 lanes of a row, in every lane */
+/* block trial of mode m for the sample of this lane: prediction from the block's reference samples (S.nxn_bord: corner, left[8],
+   above[8]; 4x4 blocks never use the smoothed ones  [ref :274-275]), residual, DST, quantiser, dequantiser, inverse, reconstruction;
+   levels go to S.nxn_lev[m] in scan order, samples to S.nxn_rec[m], the distortion to S.nxn_sse[m]   [ref :1508-1518] */
+static HD void hv_tu4_px(HvLds &S, const HvPx4 &K, const HV_LDSP u16 *lut4, int q, int ty, int tx, int m, int ok, int lane) {
+    const int p = lane & 15, y = p >> 2, x = p & 3;
+    const u8 *b = S.nxn_bord, *l = b + 1, *a = b + 9;
+    const int c = b[0];
+    m = ok ? m : 1;
+    const bool horiz = m < 18, planar = m == 0, isdc = m == 1, hor = m == 10, ver = m == 26;
+    const int ang = S.ang[m], inv = S.invang[m];
+    int pred;
+    {
+        /* angular: two neighbours on the mode's reference line r(k) -- r(k>0) the main side, r(0) the corner, r(k<0) the side samples
+           projected through the inverse angle  [ref :342-380]; pure horizontal / vertical are angle 0 plus their edge filter */
+        const int step = horiz ? x : y, along = horiz ? y : x;
+        const int off = hv_mul24(ang, step + 1), oi = off >> 5, of = off & 31, k1 = oi + along + 1, k2 = k1 + 1;
+        const int mb = horiz ? 1 : 9, sb = horiz ? 9 : 1, ik = hv_mul24(inv, k1);
+        const int i1 = k1 > 0 ? mb + hv_min(k1, 8) - 1 : (k1 == 0 ? 0 : sb + hv_min(hv_max(((128 - ik) >> 8) - 1, 0), 7));
+        const int i2 = k2 > 0 ? mb + hv_min(k2, 8) - 1 : (k2 == 0 ? 0 : sb + hv_min(hv_max(((128 - ik - inv) >> 8) - 1, 0), 7));
+        int v = (hv_mul24(32 - of, b[i1]) + hv_mul24(of, b[i2]) + 16) >> 5;
+        const int ly = l[y], ax = a[x], l0 = l[0], a0 = a[0];
+        int dc = 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) dc += l[k] + a[k];
+        dc >>= 3;
+        const int pl = (4 + hv_mul24(3 - x, ly) + hv_mul24(x + 1, a[4]) + hv_mul24(3 - y, ax) + hv_mul24(y + 1, l[4])) >> 3;
+        const int dv = (y == 0 && x == 0) ? (2 + 2 * dc + l0 + a0) >> 2 : (y == 0) ? (2 + 3 * dc + ax) >> 2 : (x == 0) ? (2 + 3 * dc + ly) >> 2 : dc;
+        v = (y == 0 && hor) ? hv_clip8(l0 + ((ax - c) >> 1)) : v;
+        v = (x == 0 && ver) ? hv_clip8(a0 + ((ly - c) >> 1)) : v;
+        pred = planar ? pl : (isdc ? dv : v);
+    }
+    const int org = S.org[ty + y][tx + x];
+    const int r = org - pred;
+    /* forward: columns (shift 1), rows (shift 8)  [ref :497-516] */
+    const int t = (hv_mul24(K.dcol[0], r) + hv_mul24(K.dcol[1], hv_row_get<4>(r)) + hv_mul24(K.dcol[2], hv_row_get<8>(r)) + hv_mul24(K.dcol[3], hv_row_get<12>(r)) + 1) >> 1;
+    const int cf = (hv_mul24(K.drow[0], hv_quad_get<0>(t)) + hv_mul24(K.drow[1], hv_quad_get<1>(t)) + hv_mul24(K.drow[2], hv_quad_get<2>(t)) + hv_mul24(K.drow[3], hv_quad_get<3>(t)) + 128) >> 8;
+    /* quantiser  [ref :540-595] */
+    const int sh = 19 + q, thr = 9 << sh >> 2, qsh = 5 + q;
+    const int av = hv_abs(cf), d = av << 14;
+    int mag;
+    if (lut4) {                                                  /* the first 2048 entries of the 4x4 level table are in LDS (cluster of four) */
+        mag = lut4[hv_min(av, 2047)];
+        if (hv_ballot(av > 2047)) { int d2; const int g = hv_quant_lut(hv_qlut<2>(S), av, d2); mag = av > 2047 ? g : mag; }
+    } else { int d2; mag = hv_quant_lut(hv_qlut<2>(S), av, d2); }
+    const int zero = hv_row_sum(hv_min(d, thr)) < thr;
+    const int lv = zero ? 0 : (cf < 0 ? -mag : mag);
+    const int dq = hv_clip16((int)((unsigned)lv << qsh));
+    /* inverse: columns with C^T (shift 7), rows (shift 12) */
+    const int t2 = hv_clip16((hv_mul24(K.tcol[0], dq) + hv_mul24(K.tcol[1], hv_row_get<4>(dq)) + hv_mul24(K.tcol[2], hv_row_get<8>(dq)) + hv_mul24(K.tcol[3], hv_row_get<12>(dq)) + 64) >> 7);
+    const int res = hv_clip16((hv_mul24(K.trow[0], hv_quad_get<0>(t2)) + hv_mul24(K.trow[1], hv_quad_get<1>(t2)) + hv_mul24(K.trow[2], hv_quad_get<2>(t2)) + hv_mul24(K.trow[3], hv_quad_get<3>(t2)) + 2048) >> 12);
+    const int rc = hv_clip8(res + pred), dd = org - rc;
+    const int sse = hv_row_sum(hv_mul24(dd, dd));
+    if (ok) {
+        S.nxn_lev[m][S.fx.scan4[hv_scan_kind(4, m)][p]] = (short)lv;
+        S.nxn_rec[m][p] = (u8)rc;
+        if (p == 0) S.nxn_sse[m] = sse;
+    }
+}
+/* bins of coeff_abs_level_remaining  [ref :1154-1169] for value v at Rice parameter k (the count hv_emit_remainder makes) */
+static HD int hv_remainder_bins(int v, int k) {
+    const int shortf = v < (3 << k);
+    const int w2 = hv_max(v - (3 << k), 0) + (1 << k);
+    const int len = 31 - hv_clz((unsigned)w2);
+    return shortf ? (v >> k) + 1 + k : 4 + 2 * len - k;
+}
+/* binarisation of the same four blocks, lane = (mode slot, scan position); needs the levels of hv_tu4_px (a wave barrier in
+   between).  Writes the mode's resolved tokens, its token / bypass-bin counts (S.nxn_magn) and last position / any-level flag.
+   [ref :1046-1087 last position, :1194-1268 one group that is both first and last, :1154-1169] */
+static HD void hv_tok4_px(HvLds &S, int m, int ok, int lane) {
+    const int ii = lane & 15, s16 = lane & 48;
+    const int v = ok ? S.nxn_lev[m][ii] : 0, av = hv_abs(v);
+    m = ok ? m : 0;
+    const unsigned nzm = (unsigned)(hv_ballot(v != 0) >> s16) & 0xffffu;
+    const int nz = __builtin_popcount(nzm), sig = nzm != 0;
+    const int last = sig ? 31 - hv_clz(nzm) : 0, start = last;
+    const int ks = hv_scan_kind(4, m);
+    /* tokens that do not exist (and everything of a lane without a mode) go to word HV_NXR_DUMMY of the row: no divergent stores */
+    HV_LDSP unsigned *row = (HV_LDSP unsigned *)S.nxn_tok[m] + HV_NXR_TOK;
+    HV_LDSP u16 *comp = (HV_LDSP u16 *)S.nxn_tok[m] + HV_NXR_COMP;
+    #define HV_NXR_DUMMY 64
+    /* ---- last_sig_coeff_{x,y}_prefix: a coordinate c < 3 is c ones and a zero, 3 is three ones; one context per bin.
+       Lanes 0..3 of the mode write the x tokens, 4..7 the y tokens ---- */
+    int nlast;
+    {
+        const int pos = S.fx.unscan4[ks][last], iy = pos >> 2, ix = pos & 3;
+        const int cx_ = ks == 2 ? iy : ix, cy_ = ks == 2 ? ix : iy;     /* the vertical scan codes the coordinates swapped */
+        const int nx = cx_ < 3 ? cx_ + 1 : 3, ny = cy_ < 3 ? cy_ + 1 : 3;
+        nlast = nx + ny;
+        const int rr = ii & 3, isy = (ii >> 2) & 1, coord = isy ? cy_ : cx_, cnt = isy ? ny : nx, ctx = (isy ? CX_LASTY : CX_LASTX) + rr;
+        const int bin = rr < coord;
+        row[(ok && ii < 8 && rr < cnt) ? (isy ? nx : 0) + rr : HV_NXR_DUMMY] = HV_RTOK(S.ftab[ctx], bin, HV_CT(ctx, bin));
+    }
+    /* ---- sig_coeff_flag of the positions below the last one: the flag's context has seen the flags of its class's earlier
+       positions, which are bits of nzm ---- */
+    {
+        const int info = S.fx.sig4[ks][ii];
+        const int cls = info & 15, mm = (info >> 4) & 3, e1 = (info >> 6) & 15, e2 = (info >> 10) & 15;
+        const int ok1 = mm >= 1 && e1 < start, ok2 = mm >= 2 && e2 < start;       /* e1 > e2: ok1 implies ok2 whenever there is a second one */
+        const int b1 = (nzm >> e1) & 1, b2 = (nzm >> e2) & 1;
+        const int k = ok1 + ok2, pre = ok1 ? (b1 | (ok2 ? b2 << 1 : 0)) : (ok2 ? b2 : 0);
+        const int bin = (nzm >> ii) & 1;
+        row[(ok && ii < start) ? nlast + start - 1 - ii : HV_NXR_DUMMY] = HV_RTOK(S.ftab[HV_FT_SIG + cls * 8 + ((1 << k) | pre)], bin, HV_CT(CX_SIG + cls, bin));
+    }
+    /* ---- the non-zero magnitudes in coding order (highest position first): item t of the mode goes to lane t ---- */
+    comp[(ok && v != 0) ? __builtin_popcount(nzm >> (ii + 1)) : 16 + ii] = (u16)av;      /* (16 + ii: the row's spare words behind) */
+    WAVE_SYNC();
+    const int t = ii, at = (ok && t < nz) ? comp[t] : 0;
+    const unsigned bigc = (unsigned)(hv_ballot(at > 1) >> s16) & 0xffffu, g2c = (unsigned)(hv_ballot(at > 2) >> s16) & 0xffffu;
+    const int n1 = hv_min(nz, 8);
+    const int fb = __builtin_ctz((bigc & 0xffu) | 0x100u);       /* the first level above 1 among the first eight; 8: none */
+    /* greater1 flags of the first eight: contexts 1, 2, 3, 3, ... up to the first level above 1, 0 after it; so context 3 has seen
+       zeros only and context 0 the flags since.  greater2 of that first one  [ref :1217-1236] */
+    {
+        const int c1 = t <= fb ? hv_min(t + 1, 3) : 0, k0 = hv_max(t - fb - 1, 0);
+        const int p0 = (int)(bigc >> ((fb + 1) & 15)) & ((1 << k0) - 1);
+        const int at_ = c1 == 0 ? HV_FT_ONE0 + ((1 << k0) | p0) : (c1 == 3 ? HV_FT_ONE3 + (t - 2) : CX_ONE + c1);
+        const int bin = at > 1;
+        row[(ok && t < n1) ? nlast + start + t : HV_NXR_DUMMY] = HV_RTOK(S.ftab[at_], bin, HV_CT(CX_ONE + c1, bin));
+        row[(ok && t == fb) ? nlast + start + n1 : HV_NXR_DUMMY] = HV_RTOK(S.ftab[CX_ABS], at > 2, HV_CT(CX_ABS, at > 2));
+    }
+    const int ntok = nlast + start + n1 + (fb < 8);
+    row[(ok && ii < 8) ? ntok + ii : HV_NXR_DUMMY] = HV_RTOK_NOP;
+    /* ---- bypass bins: a sign per level, and the remaining magnitudes with the adaptive Rice parameter  [ref :1238-1268].  The
+       parameter only moves up, by one, behind an item above 3 << parameter: from 0 behind the first item above 3, from 1 behind the
+       first item after that above 6, ... -- four ballots and four find-first-set; the bins are then counted one item per lane ---- */
+    const int more = __builtin_popcount(bigc & 0xffu) > 1;
+    const int esc = nz > 8 || more || (fb < 8 && ((g2c >> fb) & 1));
+    const int base = t < 8 ? ((bigc & ((1u << t) - 1)) ? 2 : 3) : 1;
+    const int rem = at - base, on = t < nz && esc && rem >= 0;
+    int rice = 0;
+    {
+        const unsigned e0 = (unsigned)(hv_ballot(on && at > 3) >> s16) & 0xffffu, e1 = (unsigned)(hv_ballot(on && at > 6) >> s16) & 0xffffu;
+        const unsigned e2 = (unsigned)(hv_ballot(on && at > 12) >> s16) & 0xffffu, e3 = (unsigned)(hv_ballot(on && at > 24) >> s16) & 0xffffu;
+        const int p0 = __builtin_ctz(e0 | 0x10000u);                                    /* 16: never */
+        const int p1 = __builtin_ctz((e1 & ~((2u << p0) - 1)) | 0x10000u);
+        const int p2 = __builtin_ctz((e2 & ~((2u << p1) - 1)) | 0x10000u);
+        const int p3 = __builtin_ctz((e3 & ~((2u << p2) - 1)) | 0x10000u);
+        rice = (t > p0) + (t > p1) + (t > p2) + (t > p3);
+    }
+    const int byp = nz + hv_row_sum(on ? hv_remainder_bins(rem, rice) : 0);
+    if (ok && ii == 0) { S.nxn_last[m] = last; S.nxn_sig[m] = sig; S.nxn_magn[m] = ntok | (byp << 8); }
+    #undef HV_NXR_DUMMY
+}
+/* The engine for resolved tokens: n of them at sp (16-byte chunks of four), followed by at least 8 HV_RTOK_NOP.  Per bin the LPS
+   range is a byte of the table entry picked by the range quarter (v_perm_b32), the new range `lps` or `range - lps` shifted left
+   until bit 8 is set again  [ref :914-933]; the table entries of the next four bins are in flight meanwhile, the tokens of the
+   four after those too. */
+static HD void hv_rengine_step(HvFCod &c, unsigned lps4, unsigned nx) {
+    const int lps = (int)hv_perm(lps4, 0u, (unsigned)c.range >> 6);
+    const int pre = (nx >> 8) ? lps : c.range - lps;
+    const int sh = hv_clz_nz((unsigned)pre) - 23;
+    c.range = pre << sh;
+    c.nbits -= sh;
+}
+template <typename ChunkPtr>
+static HD void hv_rengine(const HvLds &S, HvFCod &c, ChunkPtr sp, int n) {
+    if (n <= 0) return;
+    unsigned el[4], en[4];
+    {
+        const HvChunk cur = sp[0];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { el[k] = S.ctab2[cur[k] >> 16][0]; en[k] = S.ctab2[cur[k] >> 16][1]; }
+    }
+    HvChunk nxt = sp[1];
+    for (int base = 0; base < n; base += 4) {
+        const HvChunk tk = nxt;
+        nxt = sp[(base >> 2) + 2];
+        unsigned nl[4], nn[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { nl[k] = S.ctab2[tk[k] >> 16][0]; nn[k] = S.ctab2[tk[k] >> 16][1]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) hv_rengine_step(c, el[k], en[k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { el[k] = nl[k]; en[k] = nn[k]; }
+    }
+}
+/* one pass: the block trials and the binarisation of the four modes 4 * slot .. 4 * slot + 3 (whole wavefront) */
+static HD void hv_nxn_pass(HvLds &S, const HvPx4 &K, const HV_LDSP u16 *lut4, int q, int ty, int tx, int slot, int lane) {
+    const int m = 4 * slot + (lane >> 4), ok = m < HEVCE_NMODES;
+    hv_tu4_px(S, K, lut4, q, ty, tx, m, ok, lane);
+    WAVE_SYNC();
+    hv_tok4_px(S, m, ok, lane);
+    WAVE_SYNC();
+}
+
 /* a helper wavefront of the NxN chain (cluster of four): for each of the CU's four 4x4 blocks, when the chain has laid out the
    reference samples, the block trials of its 16 modes */
+#define HV_NXN_HELPERS 4
 static HDN void hv_nxn_helper(int q, HvCu cu, int h) {
     HvLds &S = HV_S;
     q = hv_uni(q); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x); h = hv_uni(h);
-    const int lane = hv_tid() & 63, m = 16 * h + (lane >> 2);
+    const int lane = hv_tid() & 63;
+    HvPx4 K;
+    hv_px4_consts(S, K, lane);
+    const HV_LDSP u16 *lut4 = hv_lut4_lds(S, 1);
     for (int s = 0; s < 4; s++) {
         while (hv_poll(&S.nxq_go) <= s) hv_spin_short();
-        hv_tu4_quad(S, q, cu.y + (s >> 1) * 4, cu.x + (s & 1) * 4, m, m < HEVCE_NMODES);
+        /* modes 8 h .. 8 h + 7, four per pass (the chain wavefront takes 32..34) */
+        for (int slot = 2 * h; slot < 2 * h + 2; slot++) hv_nxn_pass(S, K, lut4, q, cu.y + (s >> 1) * 4, cu.x + (s & 1) * 4, slot, lane);
         HV_FENCE_RELEASE();
         if (lane == 0) hv_atomic_inc(&S.nxq_done);
-        if (h == 0) {
-            /* the first helper goes on with half of the binarisation, lane = mode: greater1 / greater2 flags and the bypass-bin
-               count of every mode's block, into the second half of the mode's token row, while the chain wavefront writes the
-               prefix and significance tokens and starts its engines on them */
-            while (hv_poll(&S.nxq_done) < 3 * (s + 1)) hv_spin_short();
-            if (lane < HEVCE_NMODES) {
-                HV_LDSP u16 *tk = (HV_LDSP u16 *)S.nxn_tok[lane] + 72;
-                HvTokW<HV_LDSP u16 *, true> wm = { tk, 0, 0 };
-                HvCg g;
-                hv_cg_load(S, g, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, hv_scan_kind(4, lane), 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0), 1);
-                hv_cg_emit_mag(S, wm, g, 0);
-#pragma unroll
-                for (int i = 0; i < 8; i++) tk[HV_SLOT_TOK0 + wm.n + i] = (u16)HV_TOK_NOPF;
-                S.nxn_magn[lane] = wm.n | (wm.byp << 8);
-            }
-            HV_FENCE_RELEASE();
-            WAVE_SYNC();
-            if (lane == 0) hv_flag_set(&S.nxq_mag, s + 1);
-        }
     }
 }
 
@@ -1889,6 +2151,9 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
     q = hv_uni(q); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x);
     int total = 0;
     HV_PROF2_T0();
+    HvPx4 K;
+    if constexpr (FAST) hv_px4_consts(S, K, lane);
+    const HV_LDSP u16 *lut4 = hv_lut4_lds(S, FAST && hv_uni(helpers));
     if (lane == 0) { S.c70_len = 16; S.c70_byp = 0; }
     for (int s = 0; s < 4; s++) {
         int l, lb, a, ar;
@@ -1916,11 +2181,15 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
             S.nxn_bord[lane] = (u8)v;
         }
         WAVE_SYNC();
-        if (hv_uni(helpers)) {
-            /* three helper wavefronts do the block trials, four lanes per mode (hv_nxn_helper); wait for them */
-            HV_FENCE_RELEASE();
-            if (lane == 0) hv_flag_set(&S.nxq_go, s + 1);
-            while (hv_poll(&S.nxq_done) < 3 * (s + 1)) hv_spin_short();
+        if constexpr (FAST) {
+            /* block trials and binarisation with one lane per sample, four modes per pass (hv_nxn_pass): nine passes -- all here, or
+               eight on four helper wavefronts (hv_nxn_helper) and the last one here */
+            if (hv_uni(helpers)) {
+                HV_FENCE_RELEASE();
+                if (lane == 0) hv_flag_set(&S.nxq_go, s + 1);
+                hv_nxn_pass(S, K, lut4, q, cu.y + oy, cu.x + ox, 8, lane);
+                while (hv_poll(&S.nxq_done) < HV_NXN_HELPERS * (s + 1)) hv_spin_short();
+            } else for (int slot = 0; slot < 9; slot++) hv_nxn_pass(S, K, lut4, q, cu.y + oy, cu.x + ox, slot, lane);
         } else if (lane < HEVCE_NMODES) {
             int last;
             const int sse = hv_tu4_lane(S, q, S.nxn_bord, S.nxn_line[lane], cu.y + oy, cu.x + ox, lane, (HV_LDSP short *)S.nxn_lev[lane], (HV_LDSP u8 *)S.nxn_rec[lane], last);
@@ -1931,56 +2200,63 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
         /* rate of every candidate: lane = mode  [ref :1505-1519]; residual_coding is written even for an all-zero block */
         int cost = HV_I32MAX, idx = -1;
         if (lane < HEVCE_NMODES) {
-            u8 *cx = &S.nxn_ctx[0][lane];                          /* the chain's own context columns (same layout as a level's) */
-            for (int k = 0; k < 3; k++) { *HV_CX(CX_LASTX + k) = S.ctx_fresh[CX_LASTX + k]; *HV_CX(CX_LASTY + k) = S.ctx_fresh[CX_LASTY + k]; }
-            for (int k = 0; k < 9; k++) *HV_CX(CX_SIG + k) = S.ctx_fresh[CX_SIG + k];
-            for (int k = 0; k < 4; k++) *HV_CX(CX_ONE + k) = S.ctx_fresh[CX_ONE + k];
-            *HV_CX(CX_ABS) = S.ctx_fresh[CX_ABS];
-            *HV_CX(HV_CT_PAD) = HV_PADCV;                         /* pad context used by bypass / no-op tokens */
-            HV_LDSP u16 *tk = (HV_LDSP u16 *)S.nxn_tok[lane];
-            const int ks = hv_scan_kind(4, lane);
-            /* the two slots are laid out so that their tokens are contiguous from tk[8]; one group: no set memory */
-            HvTokW<HV_LDSP u16 *, FAST> wa = { tk, 0, 0 };
-            const int na = hv_tokenize_tu<3>(S, wa, 4, 2, ks, 0, 0, 1, S.nxn_last[lane]);
-            HvTokW<HV_LDSP u16 *, FAST> wb = { tk + na, 0, 0 };
-            HvCg g;
-            hv_cg_load(S, g, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0), 1);
-            int nb;
-            if (FAST && hv_uni(helpers)) { hv_cg_emit_sig(S, wb, g); nb = wb.n; }   /* the greater / remainder part: a helper wavefront, meanwhile (hv_nxn_helper) */
-            else nb = hv_cg_emit(S, wb, g, 0);
-#pragma unroll
-            for (int i = 0; i < 8; i++) tk[HV_SLOT_TOK0 + na + nb + i] = (u16)(FAST ? HV_TOK_NOPF : HV_TOK_NOP);
-            HV_PROF2(S, 1);
-            /* last block, only its engine to go: tell the candidates riding in the other wavefronts to wind up, so that they are
-               at the workgroup barrier when this wavefront gets there */
-            if (s == 3 && lane == 0) hv_flag_clear(&S.nxn_busy);
-            int bits;
+            int bits, ntok, nbyp;
             if constexpr (FAST) {
+                /* the mode's resolved tokens are there (hv_tok4_px): the engine has no context to look up or to write back */
+                HV_PROF2(S, 1);
+                if (s == 3 && lane == 0) hv_flag_clear(&S.nxn_busy);     /* (see below) */
+                const int mg = S.nxn_magn[lane];
+                ntok = mg & 0xff; nbyp = mg >> 8;
                 HvFCod c = { 510, 23 };
-                hv_fengine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb);
-                if (hv_uni(helpers)) {
-                    while (hv_poll(&S.nxq_mag) <= s) hv_spin_short();
-                    const int mg = S.nxn_magn[lane], nm = mg & 0xff;
-                    hv_fengine(S, c, cx, (const HV_LDSP HvChunk *)(tk + 72 + HV_SLOT_TOK0), nm);
-                    nb += nm; wb.byp += mg >> 8;
-                }
-                bits = 23 - c.nbits + wa.byp + wb.byp;
+                hv_rengine(S, c, (const HV_LDSP HvChunk *)((HV_LDSP unsigned *)S.nxn_tok[lane] + HV_NXR_TOK), ntok);
+                bits = 23 - c.nbits + nbyp;
             } else {
+                u8 *cx = &S.nxn_ctx[0][lane];                      /* the chain's own context columns (same layout as a level's) */
+                for (int k = 0; k < 3; k++) { *HV_CX(CX_LASTX + k) = S.ctx_fresh[CX_LASTX + k]; *HV_CX(CX_LASTY + k) = S.ctx_fresh[CX_LASTY + k]; }
+                for (int k = 0; k < 9; k++) *HV_CX(CX_SIG + k) = S.ctx_fresh[CX_SIG + k];
+                for (int k = 0; k < 4; k++) *HV_CX(CX_ONE + k) = S.ctx_fresh[CX_ONE + k];
+                *HV_CX(CX_ABS) = S.ctx_fresh[CX_ABS];
+                *HV_CX(HV_CT_PAD) = HV_PADCV;                     /* pad context used by bypass / no-op tokens */
+                HV_LDSP u16 *tk = (HV_LDSP u16 *)S.nxn_tok[lane];
+                const int ks = hv_scan_kind(4, lane);
+                /* the two slots are laid out so that their tokens are contiguous from tk[8]; one group: no set memory */
+                HvTokW<HV_LDSP u16 *, FAST> wa = { tk, 0, 0 };
+                const int na = hv_tokenize_tu<3>(S, wa, 4, 2, ks, 0, 0, 1, S.nxn_last[lane]);
+                HvTokW<HV_LDSP u16 *, FAST> wb = { tk + na, 0, 0 };
+                HvCg g;
+                hv_cg_load(S, g, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0), 1);
+                const int nb = hv_cg_emit(S, wb, g, 0);
+#pragma unroll
+                for (int i = 0; i < 8; i++) tk[HV_SLOT_TOK0 + na + nb + i] = (u16)HV_TOK_NOP;
+                HV_PROF2(S, 1);
+                /* last block, only its engine to go: tell the candidates riding in the other wavefronts to wind up, so that they are
+                   at the workgroup barrier when this wavefront gets there */
+                if (s == 3 && lane == 0) hv_flag_clear(&S.nxn_busy);
                 HvCod c;
                 hv_cod_fresh(c);
                 hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb, (HV_LDSP u16 *)S.nxn_sink[lane]);
                 hv_cod_replay(c, (const HV_LDSP HvChunk *)S.nxn_sink[lane]);
                 bits = hv_cod_bits(c);
+                ntok = na + nb; nbyp = 0;
             }
-            S.nxn_ntok[lane] = (na + nb) | ((wa.byp + wb.byp) << 8) | (bits << 20);
+            S.nxn_ntok[lane] = ntok | (nbyp << 8) | (bits << 20);
             cost = hv_rdcost(q, S.nxn_sse[lane], bits);
             idx = lane;
         }
         HV_PROF2(S, 2);
-        for (int sft = 1; sft < 64; sft <<= 1) {             /* minimum cost, the LATER mode wins ties  [ref :1521] */
-            const int oc = hv_shfl_xor(cost, sft), oi = hv_shfl_xor(idx, sft);
-            if (oc < cost || (oc == cost && oi > idx)) { cost = oc; idx = oi; }
+        /* minimum cost, the LATER mode wins ties  [ref :1521]: inside the rows of sixteen by rotations (no LDS), then over the four rows */
+#define HV_ARGMIN_STEP(OC, OI) do { const int oc_ = (OC), oi_ = (OI); const bool tk_ = oc_ < cost || (oc_ == cost && oi_ > idx); cost = tk_ ? oc_ : cost; idx = tk_ ? oi_ : idx; } while (0)
+        HV_ARGMIN_STEP(hv_row_get<8>(cost), hv_row_get<8>(idx));
+        HV_ARGMIN_STEP(hv_row_get<4>(cost), hv_row_get<4>(idx));
+        HV_ARGMIN_STEP(hv_row_get<2>(cost), hv_row_get<2>(idx));
+        HV_ARGMIN_STEP(hv_row_get<1>(cost), hv_row_get<1>(idx));
+        {
+            const int c0 = hv_shfl(cost, 0), i0 = hv_shfl(idx, 0), c1 = hv_shfl(cost, 16), i1 = hv_shfl(idx, 16), c2 = hv_shfl(cost, 32), i2 = hv_shfl(idx, 32);
+            cost = c0; idx = i0;
+            HV_ARGMIN_STEP(c1, i1);
+            HV_ARGMIN_STEP(c2, i2);                              /* (35 modes: the fourth row is empty) */
         }
+#undef HV_ARGMIN_STEP
         const int w = idx;
         if (lane < 16) {
             S.nxn_crec[oy + (lane >> 2)][ox + (lane & 3)] = S.nxn_rec[w][lane];
@@ -1996,11 +2272,21 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
         {
             const int pk = S.nxn_ntok[w];
             const int off = S.c70_len, cbf = S.nxn_sig[w], n = cbf ? (pk & 0xff) : 0;
-            const HV_LDSP u16 *src = (const HV_LDSP u16 *)S.nxn_tok[w] + HV_SLOT_TOK0;
-            const int nm = (FAST && hv_uni(helpers)) ? (S.nxn_magn[w] & 0xff) : 0, na1 = n - nm;   /* with helpers the tokens are in two pieces */
             if (lane == 0) c70[off] = (u16)HV_CT(CX_YCBF, cbf);
-            if (lane < n) c70[off + 1 + lane] = lane < na1 ? src[lane] : src[72 + lane - na1];
-            if (lane + 64 < n) c70[off + 65 + lane] = lane + 64 < na1 ? src[lane + 64] : src[72 + lane + 64 - na1];
+            if constexpr (FAST) {
+                /* the plain halves of the winner's resolved tokens (<= 32): candidate 70 meets them in another context state.  With a rider
+                   (cluster of four) they go to its wavefront's scratch tile, two blocks alternating: no round trip through the L2 */
+                const HV_LDSP unsigned *src = (const HV_LDSP unsigned *)S.nxn_tok[w] + HV_NXR_TOK;
+                if (hv_uni(helpers)) {
+                    while (hv_poll(&S.c70_rd) < s - 1) hv_spin_short();      /* the rider is through with the block before the last one (same buffer) */
+                    HV_LDSP u16 *dst = (HV_LDSP u16 *)&S.ws[5] + (s & 1) * 64;
+                    if (lane < 48) dst[lane] = lane < n ? (u16)src[hv_min(lane, 39)] : (u16)HV_TOK_NOPF;   /* whole chunks of no-ops behind, and one more for the engine's prefetch */
+                } else if (lane < n) c70[off + 1 + lane] = (u16)src[lane];
+            } else {
+                const HV_LDSP u16 *src = (const HV_LDSP u16 *)S.nxn_tok[w] + HV_SLOT_TOK0;
+                if (lane < n) c70[off + 1 + lane] = src[lane];
+                if (lane + 64 < n) c70[off + 65 + lane] = src[lane + 64];
+            }
             if constexpr (FAST) {
                 /* kept for hv_verify_nxn: the winner's levels, what the tokeniser was given, the bit count it was chosen with */
                 const int blk = (((cu.y >> 3) * 4 + (cu.x >> 3)) << 2) | s;
@@ -2154,7 +2440,7 @@ static HD void hv_level_begin(HvLds &S, const HvCu cu) {
     }
     if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = 0; L.tlen[tid] = 0; }
     if (n == 8) for (int k = tid; k < 8 * 8; k += HV_NTHREADS) (&S.nxn_crec[0][0])[k] = 0;
-    if (n == 8 && tid == 0) { S.nxn_busy = 1; S.l0_active = 71; S.c70_done = 0; S.nxq_go = 0; S.nxq_done = 0; S.nxq_mag = 0; }
+    if (n == 8 && tid == 0) { S.nxn_busy = 1; S.l0_active = 71; S.c70_done = 0; S.nxq_go = 0; S.nxq_done = 0; S.c70_rd = 0; }
 }
 
 /* chunks per slot of the candidates a wavefront is binarising: rows of HEVCE_TOKEN_SLOTS + 2 bytes, row 0 = candidate t0, in
@@ -2718,8 +3004,8 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     }
     if (hv_uni(cl) == 2) {                                       /* cluster of 4: this CU's block jobs and candidates 0..69 are another workgroup's */
         if (wv == 5) hv_c70_rider(im, hv_c70_area(s0, 1), q);      /* FAST analysis only (cl == 2); it also reports the candidate to the 8x8 workgroup */
-        if (wv >= 1 && wv <= 3) hv_nxn_helper(q, c8, wv - 1);      /* the NxN chain's block trials, 16 modes each */
-        if (wv == 4) hv_cl_peek8(S, im, lane);                    /* the 8x8 workgroup's answer, noticed while the chain runs */
+        if (wv >= 1 && wv <= 4) hv_nxn_helper(q, c8, wv - 1);      /* the NxN chain's block trials and binarisation, 8 modes each */
+        if (wv == 4) hv_cl_peek8(S, im, lane);                    /* then: the 8x8 workgroup's answer, noticed while the chain winds up */
         if (wv == 6 && k16 == 0 && m == 0 && hv_uni(S.nxv_pend)) hv_verify_nxn(lane, 1);   /* the previous CTU's NxN winners, off the critical path */
         return;
     }
@@ -2922,10 +3208,8 @@ static HD void hv_init_tables(HvLds &S, int q, int tid) {
         }
     }
     if (tid >= 128 && tid < 128 + HEVCE_NCTXP) {                                                          /* [ref :727-735] */
-        const int i = tid - 128, iv = hv_ctxinit[i], qp = 6 * q + 4;
-        int st = ((((iv >> 4) * 5 - 45) * qp) >> 4) + ((iv & 15) << 3) - 16;
-        st = hv_min(hv_max(st, 1), 126);
-        const u8 v = (u8)(st >= 64 ? (((st - 64) << 1) | 1) : ((63 - st) << 1));
+        const int i = tid - 128;
+        const u8 v = (u8)hv_ctx_fresh_value(i, q);
         S.ctx_fresh[i] = v; S.com_ctx[i] = (i == HV_CT_PAD) ? (u8)HV_PADCV : v; S.nxn_ctx[i][HV_TL - 1] = v;
     }
     if (tid == 300) { S.com.range = 510; S.com.low = 0; S.com.nbits = 23; S.com.nbytes = 0; S.com.bufbyte = 0xff; S.com.zeros = 0; S.com.nout = 0; S.com.pad = 0; S.wr = S.com; S.wr_epb = 0; }
@@ -2933,7 +3217,51 @@ static HD void hv_init_tables(HvLds &S, int q, int tid) {
 
 /* The engines' context table for the mode the workgroup is in (EXACT: ctab, FAST: ctab2 -- they share their LDS).  All threads;
    needs a barrier before the next engine runs  [ref :701-713, 914-933]. */
-static HD void hv_set_mode(HvLds &S, int exact, int tid) {
+struct HvSig4Info { u16 v[3][16]; u8 scan[3][16]; };
+constexpr HvSig4Info hv_make_sig4info() {
+    /* sig_coeff_flag of a 4x4 block, per scan kind and scan position: context class (H.265 9.3.4.2.5, sigCtx of a 4x4 block) | number
+       m of earlier-coded positions of the same class << 4 | the first of them << 6 | the second << 10 (a class has at most three
+       positions that can carry a flag: position 15 never does)  [ref :1092-1122] */
+    HvSig4Info t{};
+    constexpr int sig4[16] = HEVCE_TAB_SIG4;
+    constexpr int dg[16] = { 0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15 };   /* up-right diagonal: scan position -> raster  [ref :1130-1132] */
+    for (int kind = 0; kind < 3; kind++) {
+        int cls[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int ii = 0; ii < 16; ii++) {
+            const int pos = kind == 0 ? dg[ii] : (kind == 1 ? ii : ((ii & 3) * 4 + (ii >> 2)));
+            cls[ii] = pos == 0 ? 0 : sig4[pos];
+            t.scan[kind][pos] = (u8)ii;
+        }
+        for (int ii = 0; ii < 16; ii++) {
+            int m = 0, e[2] = { 0, 0 };
+            for (int jj = 14; jj > ii; jj--) if (cls[jj] == cls[ii] && m < 2) e[m++] = jj;
+            t.v[kind][ii] = (u16)(cls[ii] | (m << 4) | (e[0] << 6) | (e[1] << 10));
+        }
+    }
+    return t;
+}
+DEVCONST HvSig4Info hv_sig4info = hv_make_sig4info();
+static HD void hv_set_mode(HvLds &S, int exact, int q, int tid) {
+    if (!exact) {
+        /* FAST: the fresh-context resolution tables (they share their LDS with the EXACT engines' byte sinks) and the tables of
+           the one-lane-per-sample 4x4 trials (they share theirs with the EXACT trials' reference lines) */
+        for (int e = tid; e < HV_FT_SIZE; e += HV_NTHREADS) {
+            int cv, idx = 1;
+            if (e < HV_FT_SIG) cv = hv_ctx_fresh_value(e, q);
+            else if (e < HV_FT_ONE3) { cv = hv_ctx_fresh_value(CX_SIG + ((e - HV_FT_SIG) >> 3), q); idx = (e - HV_FT_SIG) & 7; }
+            else if (e < HV_FT_ONE0) { cv = hv_ctx_fresh_value(CX_ONE + 3, q); idx = 1 << (e - HV_FT_ONE3); }
+            else { cv = hv_ctx_fresh_value(CX_ONE, q); idx = e - HV_FT_ONE0; }
+            const int k = 31 - hv_clz((unsigned)hv_max(idx, 1));   /* the bins below idx's leading 1, lowest first */
+            for (int i = 0; i < k; i++) cv = hv_ctx_next(cv, (idx >> i) & 1);
+            S.ftab[e] = (e == HV_CT_PAD) ? (u8)HV_PADCV : (u8)cv;
+        }
+        if (tid < 48) {
+            S.fx.sig4[tid >> 4][tid & 15] = hv_sig4info.v[tid >> 4][tid & 15];
+            S.fx.scan4[tid >> 4][tid & 15] = hv_sig4info.scan[tid >> 4][tid & 15];
+            S.fx.unscan4[tid >> 4][hv_sig4info.scan[tid >> 4][tid & 15]] = (u8)(tid & 15);
+        }
+        if (tid >= 64 && tid < 80) S.fx.d4[tid - 64] = hv_tm.f4[tid - 64];
+    }
     if (exact) {
         if (tid < 128) {
             const int cv = tid, st = cv >> 1, mps = cv & 1;
@@ -2982,7 +3310,6 @@ static HDN void hv_c70_rider(const HevceImageDesc &im, HV_GLOBAL u16 *c70, int q
     HvLds::Level &L = S.lv[0];
     const int lane = hv_tid() & 63, pl = lane & 15, act = lane < 16;
     q = hv_uni(q);
-    HV_LDSP u16 *stage = (HV_LDSP u16 *)&S.ws[hv_tid() >> 6];     /* the block's tokens, fetched by the whole wavefront */
     u8 *cx = &L.tctx[0][pl];                                     /* context columns 0..15 of the level: its candidates 0..69 live elsewhere */
     for (int r = lane >> 4; r < HEVCE_NCTXP; r += 4) L.tctx[r][pl] = S.ent_ctx[0][r];
     WAVE_SYNC();
@@ -2996,16 +3323,15 @@ static HDN void hv_c70_rider(const HevceImageDesc &im, HV_GLOBAL u16 *c70, int q
     }
     for (int s = 0; s < 4; s++) {
         while (hv_poll(&S.c70_done) <= s) hv_spin_short();
-        const int seg = hv_uni(S.c70_seg[s]), off = seg & 0xffff, n = (seg >> 16) & 0x7fff, cbf = (seg >> 31) & 1;
-        for (int t = lane; t < n; t += 64) stage[t] = (u16)(hv_ldg_u32((const unsigned *)(c70 + ((off + 1 + t) & ~1))) >> (((off + 1 + t) & 1) << 4));
-        if (lane < 16) stage[n + lane] = (u16)HV_TOK_NOPF;          /* whole chunks, and one more for the engine's prefetch */
-        WAVE_SYNC();
+        const int seg = hv_uni(S.c70_seg[s]), n = (seg >> 16) & 0x7fff, cbf = (seg >> 31) & 1;
+        const HV_LDSP u16 *stage = (const HV_LDSP u16 *)&S.ws[hv_tid() >> 6] + (s & 1) * 64;   /* the block's tokens, padded: put there by the chain (hv_job_nxn) */
         if (act) {
             *HV_CX(HV_CT_PAD) = HV_PADCV;
             hv_fbin(S, c, HV_CX(CX_YCBF), cbf);                                                             /* [ref :1038-1043] */
             hv_fengine(S, c, cx, (const HV_LDSP HvChunk *)stage, n);   /* the same bins in all sixteen lanes, each with its own range and contexts */
         }
         WAVE_SYNC();
+        if (lane == 0) hv_flag_set(&S.c70_rd, s + 1);
     }
     while (hv_poll(&S.c70_done) < 5) hv_spin_short();
     const int pat = hv_uni(S.c70_pat) & 15;
@@ -3333,7 +3659,7 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
     if (tid == 0) { S.trace = nullptr; S.qlut = im.qlut; }
     BLOCK_SYNC();
     hv_init_tables(S, q, tid);
-    hv_set_mode(S, 0, tid);
+    hv_set_mode(S, 0, q, tid);
     if (tid == 0) { S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_ans8 = 0; S.cl_fail = 0; S.cl_pick = 0; S.cl_light = 0; S.cl_ok = 0; }
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
@@ -3464,10 +3790,12 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     hv_init_tables(S, q, tid);
     const int force_exact = (im.flags & 1) || !im.payload;      /* without the writer nothing vouches for the FAST decisions */
     const int pk_nxn = (im.flags >> 8) & 0xff, pk_wr = (im.flags >> 16) & 0xff;
-    hv_set_mode(S, force_exact, tid);
+    hv_set_mode(S, force_exact, q, tid);
     if (tid == 0) { S.poison = 0; S.nxv_pend = 0; S.poison_prev = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_ans8 = 0; S.pf.k = 0; S.cl_fail = 0; S.cl_light = 0; S.cl_ok = 0; }
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
+    const int lut4_lds = im.cluster != nullptr && im.cluster->size >= 4;   /* cluster of four: the NxN chain's helpers look the 4x4 levels up in LDS */
+    if (lut4_lds && !force_exact) hv_fill_lut4(S, tid);
     BLOCK_SYNC();
     const int ncx = W >> 5, nctu = ncx * (H >> 5);
     int ctu = 0, redone = -1, n_redo = 0, n_bad = 0;            /* redone: the CTU most recently analysed twice (test hooks fire once) */
@@ -3617,7 +3945,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
             hv_snap_restore(S, ctu, (ctu % ncx) * 32, tid);
             BLOCK_SYNC();
             if (tid == 0) { S.com = S.wr; S.poison = 0; }
-            hv_set_mode(S, 1, tid);
+            hv_set_mode(S, 1, q, tid);
             redone = ctu;
             BLOCK_SYNC();
             continue;
@@ -3648,7 +3976,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                 const HevceCoderRegs &a = S.com, &b = S.wr;
                 if (ctu != nctu - 1) n_bad += a.range != b.range || a.low != b.low || a.nbits != b.nbits || a.nbytes != b.nbytes || a.bufbyte != b.bufbyte || a.zeros != b.zeros || a.nout != b.nout;
             }
-            if (!force_exact) hv_set_mode(S, 0, tid);
+            if (!force_exact) { hv_set_mode(S, 0, q, tid); if (lut4_lds) hv_fill_lut4(S, tid); }
             BLOCK_SYNC();
         }
         ctu++;

@@ -6,8 +6,8 @@
  * cpu_baseline leg of bench.py may load this file's shared object; the product
  * library (hevc-image-encoder-lite_amd/csrc) never links, includes or calls it.
  *
- * Parity status: PINNED.  The restatement is checked (oracle/validate_oracle.py,
- * tests/test_oracle_*.py) against
+ * Parity status: PINNED.  The restatement is checked (tests/test_oracle_golden.py,
+ * tests/test_oracle_vs_ref.py; fixtures by oracle/gen_golden*.py) against
  *   - the reference's own goldens testimage_out/NN.h265 (qpd6=4, 24 images),
  *   - the real reference compiled from /root/reference/src into oracle/_ref/
  *     (all 24 Kodak images x qpd6 0..4, synthetic and odd-size images, and
@@ -385,12 +385,13 @@ typedef struct {
     int32_t  range, nbits, nbytes, bufbyte, zeros;
     uint32_t low;
     int64_t  nout;        /* bytes emitted so far, emulation-prevention bytes included */
+    int32_t  nepb;        /* how many of them are emulation-prevention bytes (only read by the FAST-rule check below) */
     uint8_t *sink;        /* NULL = counting coder (trials, analysis); else bytes are stored */
 } Coder;
 typedef struct { uint8_t s[NCTX]; } Ctxs;
 
 static void coder_init(Coder *c, uint8_t *sink) {     /* [ref HEVCe.c:809-812] */
-    c->range = 510; c->low = 0; c->nbits = 23; c->nbytes = 0; c->bufbyte = 0xff; c->zeros = 0; c->nout = 0; c->sink = sink;
+    c->range = 510; c->low = 0; c->nbits = 23; c->nbytes = 0; c->bufbyte = 0xff; c->zeros = 0; c->nout = 0; c->nepb = 0; c->sink = sink;
 }
 static void ctxs_init(Ctxs *x, int q) {               /* [ref HEVCe.c:727-735, 762-785] */
     int i, qp = 6 * q + 4;
@@ -404,11 +405,20 @@ static void ctxs_init(Ctxs *x, int q) {               /* [ref HEVCe.c:727-735, 7
 static inline int64_t coder_bits(const Coder *c) {    /* [ref HEVCe.c:835-837] */
     return 8 * (c->nout + c->nbytes) + 23 - c->nbits;
 }
+/* ---- the product's FAST decision rule, restated for a differential check (tests/test_fast_rule.py) ----
+   The HIP kernel's trial engines carry the range half of the coder only, so the bit count they cost a candidate with is
+   CABAClen minus 8 x (emulation-prevention bytes put during the trial); the product then re-analyses, with exact bit counts,
+   every CTU (a) in whose final syntax the stream writer put such a byte or (b) one of whose 64 NxN sub-search winners had one.
+   With g_fast_rule set the analysis below decides by that rule and records (a) / (b); orc_analyse_fast_rule re-does flagged
+   CTUs exactly.  Whether the outcome always equals the reference's is what the check is for (it must: DESIGN.md 4.1). */
+static __thread int g_fast_rule = 0, g_poison = 0;
+static __thread long long g_trial_epb = 0;            /* trial encodes (any CU level, any candidate) that put such a byte: how often the rule matters */
+static inline int64_t cost_bits(const Coder *c) { return coder_bits(c) - (g_fast_rule ? 8 * (int64_t)c->nepb : 0); }
 static void coder_out(Coder *c, int byte) {           /* [ref HEVCe.c:821-832] start-code emulation prevention */
     byte &= 0xff;
     if (c->zeros >= 2 && byte <= 3) {
         if (c->sink) c->sink[c->nout] = 3;
-        c->nout++; c->zeros = 0;
+        c->nout++; c->zeros = 0; c->nepb++;
     }
     if (c->sink) c->sink[c->nout] = (uint8_t)byte;
     c->nout++;
@@ -739,7 +749,7 @@ static void search_cu(Enc *E, int y, int x, int n, int L, int LB, int A, int AR)
             sub_avail(s, L, LB, A, AR, &l, &lb, &a, &ar);
             search_cu(E, y + (s >> 1) * h, x + (s & 1) * h, h, l, lb, a, ar);
         }
-        best = rd_cost(q, block_sse(E, y, x, n), (int)(coder_bits(&E->cod) - coder_bits(&c0)));
+        best = rd_cost(q, block_sse(E, y, x, n), (int)(cost_bits(&E->cod) - cost_bits(&c0)));
         for (i = 0; i < n; i++) memcpy(keep + i * n, rec + (size_t)i * W, (size_t)n);
     }
 
@@ -750,7 +760,8 @@ static void search_cu(Enc *E, int y, int x, int n, int L, int LB, int A, int AR)
         int sse = tu_trial(q, n, m, &R, org, CTU, lev, trial), cost;
         put_split_cu(&tc, &tx, n, 0, split_inc);
         put_cu(&tc, &tx, n, 0, &m, &ml, &ma, lev, n);
-        cost = rd_cost(q, sse, (int)(coder_bits(&tc) - coder_bits(&c0)));
+        cost = rd_cost(q, sse, (int)(cost_bits(&tc) - cost_bits(&c0)));
+        g_trial_epb += tc.nepb != c0.nepb;
         if (best >= cost) {
             best = cost; E->cod = tc; E->cx = tx;
             memcpy(keep, trial, (size_t)n * n);
@@ -776,7 +787,8 @@ static void search_cu(Enc *E, int y, int x, int n, int L, int LB, int A, int AR)
         }
         put_split_cu(&tc, &tx, n, 0, split_inc);
         put_cu(&tc, &tx, n, 1, &m, &ml, &ma, lev, n);
-        cost = rd_cost(q, block_sse(E, y, x, n), (int)(coder_bits(&tc) - coder_bits(&c0)));
+        cost = rd_cost(q, block_sse(E, y, x, n), (int)(cost_bits(&tc) - cost_bits(&c0)));
+        g_trial_epb += tc.nepb != c0.nepb;
         if (best >= cost) {
             best = cost; E->cod = tc; E->cx = tx;
             for (i = 0; i < n; i++) memcpy(keep + i * n, rec + (size_t)i * W, (size_t)n);
@@ -790,7 +802,7 @@ static void search_cu(Enc *E, int y, int x, int n, int L, int LB, int A, int AR)
         Coder tc = c0; Ctxs tx = x0;
         int modes[4] = { -1, -1, -1, -1 }, lefts[4], aboves[4], cost;
         for (s = 0; s < 4; s++) {
-            int l, lb, a, ar, sub[16], sbest = I32MAX;
+            int l, lb, a, ar, sub[16], sbest = I32MAX, wepb = 0;
             uint8_t *srec = rec + (size_t)(s >> 1) * 4 * W + (s & 1) * 4;
             sub_avail(s, L, LB, A, AR, &l, &lb, &a, &ar);
             fetch_refs(&R, 4, srec, W, l, lb, a, ar);
@@ -800,15 +812,17 @@ static void search_cu(Enc *E, int y, int x, int n, int L, int LB, int A, int AR)
                 coder_init(&nc, NULL);
                 sse = tu_trial(q, 4, m, &R, org + (s >> 1) * 4 * CTU + (s & 1) * 4, CTU, sub, trial);
                 put_residual(&nc, &nx, 4, m, sub, 4);           /* also for an all-zero block */
-                scost = rd_cost(q, sse, (int)coder_bits(&nc));
+                scost = rd_cost(q, sse, (int)cost_bits(&nc));
+                g_trial_epb += nc.nepb != 0;
                 if (sbest >= scost) {
-                    sbest = scost; modes[s] = m;
+                    sbest = scost; modes[s] = m; wepb = nc.nepb;
                     for (i = 0; i < 4; i++) {
                         memcpy(srec + (size_t)i * W, trial + i * 4, 4);
                         for (j = 0; j < 4; j++) lev[((s >> 1) * 4 + i) * 8 + (s & 1) * 4 + j] = sub[i * 4 + j];
                     }
                 }
             }
+            if (wepb) g_poison |= 1;                           /* the product verifies every sub-search winner through an exact coder */
         }
         lefts[0] = ml;        aboves[0] = ma;
         lefts[1] = modes[0];  aboves[1] = pm_above(E, y, x + 4);
@@ -816,7 +830,8 @@ static void search_cu(Enc *E, int y, int x, int n, int L, int LB, int A, int AR)
         lefts[3] = modes[2];  aboves[3] = modes[1];
         put_split_cu(&tc, &tx, n, 0, split_inc);
         put_cu(&tc, &tx, n, 2, modes, lefts, aboves, lev, 8);
-        cost = rd_cost(q, block_sse(E, y, x, n), (int)(coder_bits(&tc) - coder_bits(&c0)));
+        cost = rd_cost(q, block_sse(E, y, x, n), (int)(cost_bits(&tc) - cost_bits(&c0)));
+        g_trial_epb += tc.nepb != c0.nepb;
         if (best >= cost) {
             E->cod = tc; E->cx = tx;
             fill_maps(E, y, x, 8, 8, -1);
@@ -972,6 +987,69 @@ ORC_API int orc_analyse(const uint8_t *img, uint8_t *img_rcon, uint8_t *records,
         }
     free(E.cumap); free(E.pmmap);
     *ysz = E.H; *xsz = E.W;
+    return k;
+}
+
+/* orc_analyse with the product's FAST decision rule (see cost_bits): every CTU is first decided with bit counts that leave out
+   the emulation-prevention bytes of the trial encodes; a CTU in whose final syntax such a byte occurs (what the product's stream
+   writer reports) or one of whose NxN sub-search winners has one (what hv_verify_nxn reports) is decided again from its start
+   with exact bit counts.  stats (4 ints, optional): CTUs, CTUs decided twice, trial encodes with such a byte in FAST passes
+   (low / high 31 bits).  The outputs must equal orc_analyse's. */
+ORC_API int orc_analyse_fast_rule(const uint8_t *img, uint8_t *img_rcon, uint8_t *records, int32_t *state_out,
+                                  int *ysz, int *xsz, int q, int32_t *stats) {
+    Enc E;
+    int y, x, i, j, k = 0, redo = 0;
+    long long events = 0;
+    uint8_t *cu0, *pm0;
+    build_tables();
+    memset(&E, 0, sizeof E);
+    E.q = q; E.srcH = *ysz; E.srcW = *xsz; E.src = img;
+    E.H = (imin(*ysz, MAXDIM) + CTU - 1) / CTU * CTU;
+    E.W = (imin(*xsz, MAXDIM) + CTU - 1) / CTU * CTU;
+    E.mw = E.W / 4;
+    E.rec = img_rcon;
+    E.cumap = (uint8_t *)malloc((size_t)(E.H / 4) * E.mw);
+    E.pmmap = (uint8_t *)malloc((size_t)(E.H / 4) * E.mw);
+    cu0 = (uint8_t *)malloc((size_t)(E.H / 4) * E.mw);
+    pm0 = (uint8_t *)malloc((size_t)(E.H / 4) * E.mw);
+    memset(E.cumap, 32, (size_t)(E.H / 4) * E.mw);
+    memset(E.pmmap, M_DC, (size_t)(E.H / 4) * E.mw);
+    coder_init(&E.cod, NULL);
+    ctxs_init(&E.cx, q);
+    E.fresh = E.cx;
+    for (y = 0; y < E.H; y += CTU)
+        for (x = 0; x < E.W; x += CTU, k++) {
+            const Coder c0 = E.cod;                              /* the CTU's start: coder, contexts, maps (its samples are rewritten anyway) */
+            const Ctxs x0 = E.cx;
+            int pass;
+            memcpy(cu0, E.cumap, (size_t)(E.H / 4) * E.mw); memcpy(pm0, E.pmmap, (size_t)(E.H / 4) * E.mw);
+            for (i = 0; i < CTU; i++) for (j = 0; j < CTU; j++) E.org[i][j] = (uint8_t)src_at(&E, y + i, x + j);
+            E.rec_out = (Record *)(records + (size_t)k * REC_BYTES);
+            E.cy = y; E.cx0 = x;
+            for (pass = 0; pass < 2; pass++) {
+                const long long ev0 = g_trial_epb;
+                memset(E.rec_out, 0, REC_BYTES);
+                g_fast_rule = pass == 0; g_poison = 0;
+                search_cu(&E, y, x, CTU, x > 0, 0, y > 0, y > 0 && x + CTU < E.W);
+                enc_terminate(&E.cod, y + CTU >= E.H && x + CTU >= E.W);
+                g_fast_rule = 0;
+                if (pass == 1) break;
+                events += g_trial_epb - ev0;
+                if (!g_poison && E.cod.nepb == c0.nepb) break;   /* nothing the product's checks would object to */
+                redo++;
+                E.cod = c0; E.cx = x0;
+                memcpy(E.cumap, cu0, (size_t)(E.H / 4) * E.mw); memcpy(E.pmmap, pm0, (size_t)(E.H / 4) * E.mw);
+            }
+            if (state_out) {
+                int32_t *s = state_out + (size_t)k * 8;
+                s[0] = E.cod.range; s[1] = (int32_t)E.cod.low; s[2] = E.cod.nbits; s[3] = E.cod.nbytes;
+                s[4] = E.cod.bufbyte; s[5] = E.cod.zeros; s[6] = (int32_t)(E.cod.nout & 0x7fffffff);
+                s[7] = (int32_t)(coder_bits(&E.cod) & 0x7fffffff);
+            }
+        }
+    free(E.cumap); free(E.pmmap); free(cu0); free(pm0);
+    *ysz = E.H; *xsz = E.W;
+    if (stats) { stats[0] = k; stats[1] = redo; stats[2] = (int32_t)(events & 0x7fffffff); stats[3] = (int32_t)(events >> 31); }
     return k;
 }
 

@@ -132,3 +132,19 @@ def gen_g2(h, w, noise, seed=0x1234ABCD):
     tri = lambda t, P: np.abs((t % (2 * P)) - P)
     v = 32 + tri(x, 128) + tri(y, 64) + r
     return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def analyse_fast_rule(img, q):
+    """orc_analyse_fast_rule: the analysis decided with the PRODUCT's rule (bit counts without the trial encodes' emulation-prevention
+    bytes, flagged CTUs decided again exactly).  Returns (records, rcon, state, stats = [CTUs, decided twice, trial encodes with such a byte])."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    H, W = pad32(h), pad32(w)
+    nctu = (H // 32) * (W // 32)
+    rec = np.zeros((nctu, 2176), np.uint8)
+    st = np.zeros((nctu, 8), np.int32)
+    rcon = np.zeros((H, W), np.uint8)
+    stats = np.zeros(4, np.int32)
+    ys, xs = C.c_int(h), C.c_int(w)
+    lib().orc_analyse_fast_rule(_p(img), _p(rcon), _p(rec), _p(st, _i32p), C.byref(ys), C.byref(xs), C.c_int(q), _p(stats, _i32p))
+    return rec, rcon, st, [int(stats[0]), int(stats[1]), int(stats[2]) + (int(stats[3]) << 31)]
