@@ -191,10 +191,12 @@ def main():
     go = (not args.no_extras) and all_max(-left()) < -120.0          # every rank takes the same decision
     if go:
         # ---- BASELINE.json configs[2] / SURVEY 8(d) config 3: 1024 x 1920x1080, this rank's longest-first shard, launches of <= 256
-        n3, h3, w3, uniq = 1024, 1080, 1920, 4
+        n3, h3, w3, uniq = 1024, 1080, 1920, 8
+        with open(os.path.join(ROOT, "tests", "golden", "manifest_1080p.json")) as f:
+            gold3 = {r["index"]: r["sha256"][:16] for r in json.load(f)}       # the REAL reference's streams of pictures 0..7 (oracle/gen_golden_1080p.py)
         sizes = [(h3, w3)] * n3
         mine = D.shard_batch(sizes, world)[rank]
-        pics = {k: wl.gen_g2(h3, w3, 16, seed=0x1234ABCD + k) for k in sorted({i % uniq for i in mine})}   # 4 different pictures: short host side
+        pics = {k: wl.gen_g2(h3, w3, 16, seed=0x1234ABCD + k) for k in sorted({i % uniq for i in mine})}   # 8 different pictures: short host side
         sync()
         t3 = time.perf_counter()
         launches = []
@@ -213,13 +215,13 @@ def main():
         dt3 = all_max(time.perf_counter() - t3)
         if rank == 0:
             table = sorted(tuple(x) for part in got for x in json.loads(part[0].decode()))
-            ok = [i for i, _ in table] == list(range(n3)) and all(hsh == table[i % uniq][1] for i, hsh in table)
+            ok = [i for i, _ in table] == list(range(n3)) and all(hsh == gold3[i % uniq] for i, hsh in table)
             H3, W3 = hevce.pad32(h3), hevce.pad32(w3)
             extras["config3_batch_1024x1080p"] = {
                 "value": round(H3 * W3 * n3 / dt3 / 1e6, 2), "unit": "Mpixels/s", "wall_s": round(dt3, 2), "pictures": n3,
                 "pictures_this_rank": len(mine), "launches_this_rank": len(launches), "kernel_ms_per_launch": [round(x, 1) for x in launches],
                 "includes": "H2D uploads, kernels, D2H of the streams, SHA-256 of every stream, gather of the hash table",
-                "all_streams_collected_and_consistent": bool(ok)}
+                "parity_ok": bool(ok), "parity_against": "tests/golden/manifest_1080p.json (real reference, pictures 0..7; picture i of the batch = picture i mod 8)"}
     if go and all_max(-left()) < -60.0:
         # ---- BASELINE.json configs[3] / config 4: one 16384x16384 picture as 256 tile-pictures of 1024x1024, this rank's tiles
         big, tile = 16384, 1024
@@ -237,12 +239,20 @@ def main():
             jb.run()
             k4 = jb.timings()["kernel_ms"]
             nbytes = sum(len(jb.stream(j)) for j in range(len(mine)))
+            with open(os.path.join(ROOT, "tests", "golden", "manifest_fullsize.json")) as f:
+                gold4 = {r["name"]: r["sha256"] for r in json.load(f)}
+            chk4 = {}
+            for j, t in enumerate(mine):
+                nm = f"tile_r{t // cols}_c{t % cols}"
+                if nm in gold4 and (t // cols) in band:               # a tile of a band that really is that row of the big picture
+                    chk4[nm] = hashlib.sha256(jb.stream(j)).hexdigest() == gold4[nm]
         sync()
         dt4 = all_max(time.perf_counter() - t4)
         if rank == 0:
             extras["config4_16384x16384_as_256_tiles"] = {
                 "value": round(big * big / dt4 / 1e6, 2), "unit": "Mpixels/s", "wall_s": round(dt4, 2), "tiles": len(tiles), "tiles_this_rank": len(mine),
                 "kernel_ms": round(k4, 1), "stream_bytes_this_rank": nbytes,
+                "parity_ok": (all(chk4.values()) if chk4 else None), "tiles_checked": sorted(chk4),
                 "note": "tile-pictures with their own headers (the reference crops at 8192); parity per tile: tests/test_gpu_tiles.py"}
 
     if rank == 0:
@@ -265,6 +275,12 @@ def main():
             "ctus_analysed_twice": redo, "coder_mismatches": bad,
             "stream_bytes": len(first), "stream_sha256": hashlib.sha256(first).hexdigest(),
         }
+        if (args.height, args.width, args.qpd6) == (2160, 3840, 2):
+            with open(os.path.join(ROOT, "tests", "golden", "manifest_fullsize.json")) as f:
+                g = [r for r in json.load(f) if r["name"] == "bench_4k"][0]
+            line["parity_ok"] = bool(line["stream_sha256"] == g["sha256"] and len(first) == g["len"])   # rank 0's picture against the REAL reference (oracle/gen_golden_fullsize.py)
+        else:
+            line["parity_ok"] = None
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(img, args.qpd6)

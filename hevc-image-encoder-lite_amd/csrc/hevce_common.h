@@ -89,7 +89,23 @@ typedef struct HevceNxn {      /* analysis workgroup -> 8x8 workgroup, once per 
 /* mailboxes: msg / res 0: 16x16, 1: 32x32, msg 2: 8x8 (clusters of four: one message per 16x16 quad); the 8x8 answers alternate between
    res[2] and res[3] and the NxN reports between nxn[0] and nxn[1] (by the parity of the CU's number), so that neither side can
    overwrite what the other is still reading */
-typedef struct HevceCluster { HevceMsg msg[3]; HevceRes res[4]; HevceNxn nxn[2]; int32_t error; int32_t size; int32_t pad_[2]; } HevceCluster;
+/* clusters of five: the stream writer is a workgroup of its own, several CTUs behind the analysis.  The chain workgroup publishes how many
+   CTUs have final decision records (`go`); the writer encodes them and reports, per CTU, whether it put an emulation-prevention byte
+   (`wbad`: the FAST decisions of that CTU are then not vouched for).  The chain goes back to that CTU -- its start state, up to seven CTUs
+   back, is in `snap`; the exact coder registers there are the writer's, `wregs` -- analyses it with the EXACT engines, and starts a new
+   EPOCH: the writer goes back to the same CTU (its own ring of states) and encodes it again.  Every status word carries its epoch. */
+typedef struct HevceWrx {
+    uint64_t go;               /* chain : epoch << 32 | CTUs whose records are final (0x7fffffff: exit) */
+    uint64_t wdone;            /* writer: epoch << 32 | CTUs written */
+    uint64_t wbad;             /* writer: epoch << 32 | 1 + the first CTU of the epoch it objects to (bit 30: its range differs from the analysis'); 0: none */
+    int32_t  rst;              /* chain : the CTU the current epoch restarted at */
+    int32_t  pad_[9];
+    HevceCoderRegs wregs[8];   /* writer: its registers at the start of CTU c, [c & 7] */
+    int32_t  crange[8];        /* chain : the analysis' range at the start of CTU c */
+    int32_t  xflag[8];         /* chain : CTU c was analysed EXACT (its emulation-prevention bytes are part of its bit counts) */
+    uint8_t  snap[8][192];     /* chain : what CTU c starts from (HvLds::Snap) */
+} HevceWrx;
+typedef struct HevceCluster { HevceMsg msg[3]; HevceRes res[4]; HevceNxn nxn[2]; int32_t error; int32_t size; int32_t pad_[2]; HevceWrx wrx; } HevceCluster;
 
 /* one image of a batch, as the kernel sees it (all pointers are device pointers) */
 typedef struct HevceImageDesc {

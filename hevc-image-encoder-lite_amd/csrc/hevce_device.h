@@ -1942,11 +1942,11 @@ static HD int hv_row_sum(int v) { v += hv_row_get<8>(v); v += hv_row_get<4>(v); 
 /* block trial of mode m for the sample of this lane: prediction from the block's reference samples (S.nxn_bord: corner, left[8],
    above[8]; 4x4 blocks never use the smoothed ones  [ref :274-275]), residual, DST, quantiser, dequantiser, inverse, reconstruction;
    levels go to S.nxn_lev[m] in scan order, samples to S.nxn_rec[m], the distortion to S.nxn_sse[m]   [ref :1508-1518] */
-static HD void hv_tu4_px(HvLds &S, const HvPx4 &K, const HV_LDSP u16 *lut4, int q, int ty, int tx, int m, int ok, int lane) {
+struct HvPx4Out { int lv, rc, sse, si; };                    /* this sample's level, its scan position, its reconstruction; the block's distortion */
+static HD HvPx4Out hv_tu4_px_core(HvLds &S, const HvPx4 &K, const HV_LDSP u16 *lut4, const u8 *b, int q, int ty, int tx, int m, int lane) {
     const int p = lane & 15, y = p >> 2, x = p & 3;
-    const u8 *b = S.nxn_bord, *l = b + 1, *a = b + 9;
+    const u8 *l = b + 1, *a = b + 9;
     const int c = b[0];
-    m = ok ? m : 1;
     const bool horiz = m < 18, planar = m == 0, isdc = m == 1, hor = m == 10, ver = m == 26;
     const int ang = S.ang[m], inv = S.invang[m];
     int pred;
@@ -1990,11 +1990,17 @@ static HD void hv_tu4_px(HvLds &S, const HvPx4 &K, const HV_LDSP u16 *lut4, int 
     const int t2 = hv_clip16((hv_mul24(K.tcol[0], dq) + hv_mul24(K.tcol[1], hv_row_get<4>(dq)) + hv_mul24(K.tcol[2], hv_row_get<8>(dq)) + hv_mul24(K.tcol[3], hv_row_get<12>(dq)) + 64) >> 7);
     const int res = hv_clip16((hv_mul24(K.trow[0], hv_quad_get<0>(t2)) + hv_mul24(K.trow[1], hv_quad_get<1>(t2)) + hv_mul24(K.trow[2], hv_quad_get<2>(t2)) + hv_mul24(K.trow[3], hv_quad_get<3>(t2)) + 2048) >> 12);
     const int rc = hv_clip8(res + pred), dd = org - rc;
-    const int sse = hv_row_sum(hv_mul24(dd, dd));
+    HvPx4Out o;
+    o.lv = lv; o.rc = rc; o.sse = hv_row_sum(hv_mul24(dd, dd)); o.si = S.fx.scan4[hv_scan_kind(4, m)][p];
+    return o;
+}
+static HD void hv_tu4_px(HvLds &S, const HvPx4 &K, const HV_LDSP u16 *lut4, int q, int ty, int tx, int m, int ok, int lane) {
+    m = ok ? m : 1;
+    const HvPx4Out o = hv_tu4_px_core(S, K, lut4, S.nxn_bord, q, ty, tx, m, lane);
     if (ok) {
-        S.nxn_lev[m][S.fx.scan4[hv_scan_kind(4, m)][p]] = (short)lv;
-        S.nxn_rec[m][p] = (u8)rc;
-        if (p == 0) S.nxn_sse[m] = sse;
+        S.nxn_lev[m][o.si] = (short)o.lv;
+        S.nxn_rec[m][lane & 15] = (u8)o.rc;
+        if ((lane & 15) == 0) S.nxn_sse[m] = o.sse;
     }
 }
 /* bins of coeff_abs_level_remaining  [ref :1154-1169] for value v at Rice parameter k (the count hv_emit_remainder makes) */
@@ -3499,6 +3505,397 @@ static HD void hv_cl_store_rcon(HvLds &S, const HevceImageDesc &im, const HvCu c
     }
 }
 
+/* --------------------------------------------------------------------------------------------- */
+/* The 8x8 workgroup (cluster of four) with one lane per sample: candidates 0..69 of an 8x8 CU.                                 */
+/*   TU-split candidates 35..69 (four 4x4 blocks, each predicted from the candidate's own reconstruction of the ones before):    */
+/*     block trials by hv_tu4_px, four modes per pass, block after block;                                                        */
+/*   single-block candidates 0..34: block trials by hv_job_single<8> as before;                                                  */
+/*   binarisation of both by hv_tokgrp (lane = (candidate slot, scan position of a 4x4 group), group after group in coding        */
+/*   order) as RESOLVED byte tokens -- context byte << 1 | bin, the index of the engine's table entry: the state a bin meets is    */
+/*   the candidate's context byte at the group's start (its context column, L.tctx) advanced by the bins of the same context      */
+/*   before it in the group, four at a time through the table t4; the column is advanced at the group's end -- and engines with    */
+/*   one lane per candidate (hv_bengine) whose loop has no memory access on its dependency chain.                                 */
+/* Work items (five block-trial jobs, nine TU-split slots, nine binarisation slots) are handed out by an LDS counter.            */
+/* --------------------------------------------------------------------------------------------- */
+/* run-time guard against the control-flow miscompilation described at hv_w8_cu's work loop: a work item must start with all 64 lanes;
+   otherwise the cluster is flagged (the chain workgroup gives the picture up, the host encodes it again without clusters) */
+#ifdef HEVCE_EMU
+#define HV_CHECK_FULL_WAVE(im) do { } while (0)
+#else
+#define HV_CHECK_FULL_WAVE(im) do { if (__ballot(1) != ~0ull && (im).cluster) (im).cluster->error = 5; } while (0)
+#endif
+#if defined(HEVCE_W8DBG) && !defined(HEVCE_EMU)
+#define HV_W8DBG(im, code) do { if ((im).trace && (hv_tid() & 63) == 0) { ((volatile int *)(im).trace)[200 + (hv_tid() >> 6)] = (code); __threadfence_system(); } } while (0)
+#else
+#define HV_W8DBG(im, code) do { } while (0)
+#endif
+struct HvW8 {                                                /* lives in S.lv[1..2]: the enclosing CUs' candidates are other workgroups' business */
+    u8  t4[128][32];                                         /* context byte after k <= 4 bins: [byte][1 << k | bins], the first bin = bit 0 */
+    alignas(16) u8 tok[70][176];                             /* the candidates' resolved tokens (<= 150) and at least 16 pad tokens behind */
+    u16 sigmask[35][16];                                     /* per row of S.sigtab and scan position: the positions of the same context */
+    u8  crec[35][64];                                        /* TU-split candidates: the reconstruction so far */
+    u8  bord[36][20];                                        /* ... the reference samples of the current block: corner, left[8], above[8] (row 35: lanes without a mode) */
+    short lev4[35][16];                                      /* ... its levels in scan order */
+    u16 comp[35][16];                                        /* a slot's non-zero magnitudes in coding order (per TU-split mode / single candidate) */
+    int ntok[70], nbyp[70];
+    int work, tdone[5];
+};
+static_assert(sizeof(HvW8) <= 2 * sizeof(HvLds::Level), "HvW8 must fit the two unused candidate levels");
+static HD HvW8 &hv_w8(HvLds &S) { return *(HvW8 *)&S.lv[1]; }
+static HD void hv_w8_init(HvLds &S, int tid) {               /* once per launch (after hv_init_sigtab and a barrier) */
+    HvW8 &W = hv_w8(S);
+    for (int e = tid; e < 128 * 32; e += HV_NTHREADS) {
+        const int idx = e & 31, k = 31 - hv_clz((unsigned)hv_max(idx, 1));
+        int cv = e >> 5;
+        if (cv < 126) for (int i = 0; i < k; i++) cv = hv_ctx_next(cv, (idx >> i) & 1);
+        W.t4[e >> 5][idx] = (u8)cv;
+    }
+    for (int e = tid; e < 35 * 16; e += HV_NTHREADS) {
+        const u8 *tab = S.sigtab[e >> 4];
+        int m = 0;
+        for (int j = 0; j < 16; j++) m |= (tab[j] == tab[e & 15]) << j;
+        W.sigmask[e >> 4][e & 15] = (u16)m;
+    }
+}
+/* context byte e after k <= 8 bins (the first one = bit 0 of bits): two table steps */
+static HD int hv_t4_bits(const HvW8 &W, int e, int bits, int k) {
+    const int k1 = hv_min(k, 4), k2 = k - k1;
+    const int s1 = W.t4[e][(1 << k1) | (bits & ((1 << k1) - 1))];
+    return W.t4[s1][(1 << k2) | ((bits >> 4) & ((1 << k2) - 1))];
+}
+/* ... after the bins nzm holds at the positions of mask `above`, highest position first (any number of them: four per step;
+   the loop is wave-uniform) */
+static HD int hv_t4_walk(const HvW8 &W, int e, unsigned above, unsigned nzm) {
+    int st = e;
+    while (hv_ballot(above != 0)) {
+        int bits = 0, k = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int has = above != 0, pz = 31 - hv_clz(above | 1u);
+            bits |= (has ? (int)((nzm >> pz) & 1) : 0) << k;
+            k += has;
+            above &= ~(1u << pz);
+        }
+        st = W.t4[st][(1 << k) | bits];
+    }
+    return st;
+}
+struct HvGrp {                                               /* what the lanes of a candidate slot carry from group to group (the same in all sixteen) */
+    int cur, byp, g1;                                        /* tokens so far, bypass bins so far, the last group with levels had one above 1 */
+};
+/* One 4x4 coefficient group of candidate t (lane = (slot, scan position ii)): v = the lane's level, or 0 outside a coded group.
+   n = 4 / 8 (transform size), cg / cg_last / last / nb as in hv_cg_load; appends the group's resolved tokens to W.tok[t], advances
+   the candidate's context column.  `ok` = the slot holds a candidate.  [ref :1194-1268] */
+static HD void hv_tokgrp(HvLds &S, HvW8 &W, HvLds::Level &L, HvGrp &G, int t, int ok, int v, int n, int kind, int cg, int cg_last, int lastpos, int cgs, int nb, int lane) {
+    const int ii = lane & 15, s16 = lane & 48, slot4 = (hv_tid() >> 6) * 4 + (lane >> 4);
+    const int coded = ok && cg <= cg_last, first_cg = cg == 0, at_last = cg == cg_last;
+    v = (coded && cgs) ? v : 0;
+    const int av = hv_abs(v);
+    const unsigned nzm = (unsigned)(hv_ballot(v != 0) >> s16) & 0xffffu;
+    const int nz = __builtin_popcount(nzm);
+    const int start = at_last ? (lastpos & 15) : 15;
+    u8 *col = &L.tctx[0][t];                                     /* the candidate's context column */
+    u8 *tk = W.tok[t];
+    #define HV_TK_DUMMY 175
+    int cur = G.cur;
+    /* coded_sub_block_flag */
+    {
+        const int on = coded && !first_cg && !at_last, ctx = CX_SIGCG + (nb != 0), e = col[ctx * HV_TL];
+        if (on && ii == 0) { tk[cur] = (u8)((e << 1) | cgs); col[ctx * HV_TL] = (u8)S.ctab2[(e << 1) | cgs][1]; }
+        cur += on;
+    }
+    const int body = coded && (cgs || first_cg);
+    /* significance flags, highest scan position first; position 0 of a later group is inferred when nothing else is set */
+    {
+        const int any_above0 = (nzm >> 1) != 0;
+        unsigned onm = (start >= 15 ? 0xffffu : ((2u << start) - 1)) & (at_last ? ~(1u << start) : 0xffffu);
+        onm &= (first_cg || any_above0) ? 0xffffu : 0xfffeu;
+        onm = body ? onm : 0;
+        const int row = hv_sigtab_index(n, kind, nb, first_cg);
+        const int ctx = CX_SIG + S.sigtab[row][ii];
+        const unsigned cm = (unsigned)W.sigmask[row][ii] & onm;     /* coded positions of my context */
+        const int e = col[ctx * HV_TL];
+        const int on = (onm >> ii) & 1, bin = (nzm >> ii) & 1;
+        const int st = hv_t4_walk(W, e, on ? (cm & ~((2u << ii) - 1)) : 0u, nzm);
+        tk[on ? cur + __builtin_popcount(onm >> (ii + 1)) : HV_TK_DUMMY] = (u8)((st << 1) | bin);
+        if (on && (cm & ((1u << ii) - 1)) == 0) col[ctx * HV_TL] = (u8)S.ctab2[(st << 1) | bin][1];   /* the context's last flag of the group */
+        cur += __builtin_popcount(onm);
+    }
+    /* the non-zero magnitudes in coding order: item i of the slot goes to lane i */
+    u16 *comp = W.comp[slot4];
+    WAVE_SYNC();
+    if (v != 0) comp[__builtin_popcount(nzm >> (ii + 1))] = (u16)av;
+    WAVE_SYNC();
+    const int i = ii, ai = (body && i < nz) ? comp[i] : 0;
+    const unsigned bigc = (unsigned)(hv_ballot(ai > 1) >> s16) & 0xffffu, g2c = (unsigned)(hv_ballot(ai > 2) >> s16) & 0xffffu;
+    const int n1 = hv_min(nz, 8), fb = __builtin_ctz((bigc & 0xffu) | 0x100u);
+    /* greater1 flags of the first eight -- contexts 1, 2, 3, 3, ... of the group's set up to the first level above 1, 0 after it --
+       and greater2 of that one  [ref :1217-1236] */
+    {
+        const int set4 = (first_cg ? 0 : 8) + (G.g1 ? 4 : 0), set1 = (first_cg ? 0 : 2) + (G.g1 ? 1 : 0);
+        const int c1 = i <= fb ? hv_min(i + 1, 3) : 0, ctx = CX_ONE + set4 + c1;
+        const int e = col[ctx * HV_TL], bin = ai > 1;
+        const int k = c1 == 3 ? i - 2 : (c1 == 0 ? i - fb - 1 : 0);
+        const int bits = c1 == 0 ? (int)(bigc >> ((fb + 1) & 15)) : 0;
+        const int st = hv_t4_bits(W, e, bits, hv_max(k, 0));
+        const int on = i < n1;
+        tk[on ? cur + i : HV_TK_DUMMY] = (u8)((st << 1) | bin);
+        /* the last flag on a context: context 1 / 2: their only one; 3: the one at min(fb, n1 - 1) if that is >= 2; 0: the last of all */
+        const int lastc = c1 == 0 ? i == n1 - 1 : (c1 == 3 ? i == hv_min(fb, n1 - 1) : 1);
+        if (on && lastc) col[ctx * HV_TL] = (u8)S.ctab2[(st << 1) | bin][1];
+        const int e2 = col[(CX_ABS + set1) * HV_TL], b2 = ai > 2;
+        if (i == fb && fb < 8) { tk[cur + n1] = (u8)((e2 << 1) | b2); col[(CX_ABS + set1) * HV_TL] = (u8)S.ctab2[(e2 << 1) | b2][1]; }
+        cur += n1 + (fb < 8);
+    }
+    /* bypass bins: signs, remaining magnitudes with the adaptive Rice parameter (hv_tok4_px)  [ref :1238-1268] */
+    {
+        const int more = __builtin_popcount(bigc & 0xffu) > 1;
+        const int esc = nz > 8 || more || (fb < 8 && ((g2c >> fb) & 1));
+        const int base = i < 8 ? ((bigc & ((1u << i) - 1)) ? 2 : 3) : 1;
+        const int rem = ai - base, on = i < nz && esc && rem >= 0;
+        const unsigned e0 = (unsigned)(hv_ballot(on && ai > 3) >> s16) & 0xffffu, e1 = (unsigned)(hv_ballot(on && ai > 6) >> s16) & 0xffffu;
+        const unsigned e2 = (unsigned)(hv_ballot(on && ai > 12) >> s16) & 0xffffu, e3 = (unsigned)(hv_ballot(on && ai > 24) >> s16) & 0xffffu;
+        const int p0 = __builtin_ctz(e0 | 0x10000u);
+        const int p1 = __builtin_ctz((e1 & ~((2u << p0) - 1)) | 0x10000u);
+        const int p2 = __builtin_ctz((e2 & ~((2u << p1) - 1)) | 0x10000u);
+        const int p3 = __builtin_ctz((e3 & ~((2u << p2) - 1)) | 0x10000u);
+        const int rice = (i > p0) + (i > p1) + (i > p2) + (i > p3);
+        G.byp += nz + hv_row_sum(on ? hv_remainder_bins(rem, rice) : 0);
+    }
+    G.g1 = nz ? ((bigc & 0xffu) != 0) : G.g1;
+    G.cur = cur;
+    #undef HV_TK_DUMMY
+}
+/* cbf_luma and the last position of a transform block of candidate t (lanes 0..11 of the slot write the prefix bins: x then y)
+   [ref :1038-1087] */
+static HD void hv_tokhdr(HvLds &S, HvW8 &W, HvLds::Level &L, HvGrp &G, int t, int ok, int n, int lg, int kind, int cbf_ctx, int cbf, int lastpos, int lane) {
+    const int ii = lane & 15;
+    u8 *col = &L.tctx[0][t];
+    u8 *tk = W.tok[t];
+    int cur = G.cur;
+    {
+        const int e = col[cbf_ctx * HV_TL];
+        if (ok && ii == 0) { tk[cur] = (u8)((e << 1) | cbf); col[cbf_ctx * HV_TL] = (u8)S.ctab2[(e << 1) | cbf][1]; }
+        cur += ok;
+    }
+    const int on0 = ok && cbf;
+    int gy, gx, iy, ix;
+    hv_scan_cg(S, lg, kind, lastpos >> 4, gy, gx);
+    hv_scan_in(S, kind, lastpos & 15, iy, ix);
+    const int y = gy * 4 + iy, x = gx * 4 + ix, cls = lg - 2, sh = n == 4 ? 0 : 1, gmax = 2 * lg - 1;
+    const int cy_ = kind == 2 ? x : y, cx_ = kind == 2 ? y : x;
+    const int ggx = hv_last_group(cx_), ggy = hv_last_group(cy_);
+    const int nx = ggx < gmax ? ggx + 1 : gmax, ny = ggy < gmax ? ggy + 1 : gmax;
+    {
+        const int isy = ii >= 6, r = isy ? ii - 6 : ii, gg = isy ? ggy : ggx, cnt = isy ? ny : nx;
+        const int ctx = (isy ? CX_LASTY : CX_LASTX) + 5 * cls + (r >> sh), bin = r < gg, on = on0 && ii < 12 && r < cnt;
+        const int e = col[ctx * HV_TL], k = sh ? (r & 1) : 0;       /* 8x8: two bins per context, the first of them was a one */
+        const int st = W.t4[e][k ? 3 : 1];
+        if (on) {
+            tk[cur + (isy ? nx : 0) + r] = (u8)((st << 1) | bin);
+            if (!(sh && !(r & 1) && r + 1 < cnt)) col[ctx * HV_TL] = (u8)S.ctab2[(st << 1) | bin][1];   /* unless the context's second bin follows */
+        }
+    }
+    cur += on0 ? nx + ny : 0;
+    G.byp += on0 ? (ggx > 3 ? (ggx - 2) >> 1 : 0) + (ggy > 3 ? (ggy - 2) >> 1 : 0) : 0;
+    G.cur = cur;
+}
+/* the CU header of candidate t: part_mode, prev_intra_luma_pred_flag (its mpm_idx / rem_intra_luma_pred_mode are bypass bins),
+   intra_chroma_pred_mode, split_transform_flag, cbf_cb, cbf_cr -- one context each, cbf_cb / cbf_cr share one  [ref :943-1033,
+   1282-1287].  One lane of the slot. */
+static HD void hv_tokcu(HvLds &S, HvW8 &W, HvLds::Level &L, HvGrp &G, int t, int ok, int mode, int tusplit, int lane) {
+    const int ii = lane & 15;
+    u8 *col = &L.tctx[0][t];
+    u8 *tk = W.tok[t];
+    int p3[3];
+    hv_mpm(L.ml, L.ma, p3);
+    const int hit = (p3[2] == mode) ? 2 : (p3[1] == mode) ? 1 : (p3[0] == mode) ? 0 : -1;
+    if (ok && ii == 0) {
+        const int ctxs[6] = { CX_PART, CX_YPM, CX_UVPM, CX_SPLIT_TU + 2, CX_UVCBF, CX_UVCBF };
+        const int bins[6] = { 1, hit >= 0, 0, tusplit, 0, 0 };
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const int e = col[ctxs[j] * HV_TL];
+            tk[j] = (u8)((e << 1) | bins[j]);
+            col[ctxs[j] * HV_TL] = (u8)S.ctab2[(e << 1) | bins[j]][1];
+        }
+    }
+    G.cur = ok ? 6 : 0;
+    G.byp = ok ? (hit >= 0 ? 1 + (hit > 0) : 5) : 0;
+    G.g1 = 0;
+}
+/* the engine for resolved byte tokens: n of them at sp (16-byte chunks of sixteen), at least 32 pad tokens behind */
+template <typename ChunkPtr>
+static HD void hv_bengine(const HvLds &S, HvFCod &c, ChunkPtr sp, int n) {
+    if (n <= 0) return;
+    HvChunk cur = sp[0];
+    for (int base = 0; base < n; base += 16) {
+        const HvChunk nxt = sp[(base >> 4) + 1];
+#pragma unroll
+        for (int w4 = 0; w4 < 4; w4++) {
+            unsigned el[4], en[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const unsigned ix = (cur[w4] >> (8 * k)) & 0xffu; el[k] = S.ctab2[ix][0]; en[k] = S.ctab2[ix][1]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) hv_rengine_step(c, el[k], en[k]);
+        }
+        cur = nxt;
+    }
+}
+/* work item: the TU-split candidates 35 + 4 slot .. 35 + 4 slot + 3 -- per 4x4 block the reference samples from the candidate's own
+   reconstruction, the block trial, the block's tokens  [ref :1455-1471] */
+static HD void hv_w8_split_slot(HvLds &S, const HevceImageDesc &im, HvW8 &W, const HvPx4 &K, const HvCu cu, int slot, HvGLev glev, HvGRec grec, int lane) {
+    HvLds::Level &L = S.lv[0];
+    const int q = im.qpd6, ii = lane & 15, m0 = 4 * slot + (lane >> 4), ok = m0 < HEVCE_NMODES, m = ok ? m0 : 1, t = 35 + (ok ? m0 : 0);
+    const int kind = hv_scan_kind(4, m);
+    HvGrp G;
+    hv_tokcu(S, W, L, G, t, ok, m, 1, lane);
+    int total = 0;
+    for (int b = 0; b < 4; b++) {
+        int l, lb, a, ar;
+        hv_sub_avail(b, cu.L, cu.LB, cu.A, cu.AR, l, lb, a, ar);
+        const int oy = (b >> 1) * 4, ox = (b & 1) * 4, ty = cu.y + oy, tx = cu.x + ox;
+        /* reference samples: inside the CU the candidate's own reconstruction  [ref :196-257 for a 4x4 block] */
+        {
+            auto px = [&](int yy, int xx) -> int {
+                const int ry = yy - cu.y, rx = xx - cu.x;
+                return (ry >= 0 && ry < 8 && rx >= 0 && rx < 8) ? W.crec[m][ry * 8 + rx] : S.rec[yy + 1][xx + HV_RX];
+            };
+            const int corner = (l && a) ? px(ty - 1, tx - 1) : (l ? px(ty, tx - 1) : (a ? px(ty - 1, tx) : 128));
+            const int i8 = ii & 7;
+            int vl = l ? px(ty + hv_min(i8, 3), tx - 1) : corner, va = a ? px(ty - 1, tx + hv_min(i8, 3)) : corner;
+            if (i8 >= 4) { vl = lb ? px(ty + i8, tx - 1) : vl; va = ar ? px(ty - 1, tx + i8) : va; }
+            const int mb = ok ? m : 35;
+            WAVE_SYNC();
+            if (ii < 8) W.bord[mb][1 + i8] = (u8)vl; else W.bord[mb][9 + i8] = (u8)va;
+            if (ii == 0) W.bord[mb][0] = (u8)corner;
+            WAVE_SYNC();
+        }
+        const HvPx4Out o = hv_tu4_px_core(S, K, nullptr, W.bord[ok ? m : 35], q, ty, tx, m, lane);
+        if (ok) {
+            W.lev4[m][o.si] = (short)o.lv;
+            W.crec[m][(oy + (ii >> 2)) * 8 + ox + (ii & 3)] = (u8)o.rc;
+            glev[t * 1024 + b * 16 + o.si] = (short)o.lv;
+            grec[t * 1024 + (oy + (ii >> 2)) * 8 + ox + (ii & 3)] = (u8)o.rc;
+        }
+        total += o.sse;
+        WAVE_SYNC();
+        const int v = ok ? W.lev4[m][ii] : 0;
+        const unsigned nzm = (unsigned)(hv_ballot(v != 0) >> (lane & 48)) & 0xffffu;
+        const int cbf = nzm != 0, last = cbf ? 31 - hv_clz(nzm) : 0;
+        G.g1 = 0;
+        hv_tokhdr(S, W, L, G, t, ok, 4, 2, kind, CX_YCBF, cbf, last, lane);
+        hv_tokgrp(S, W, L, G, t, ok && cbf, v, 4, kind, 0, 0, last, cbf, 0, lane);
+    }
+    if (ok) {
+        W.tok[t][G.cur + ii] = (u8)(HV_PADCV << 1);
+        if (ii == 0) { L.tsse[t] = total; W.ntok[t] = G.cur; W.nbyp[t] = G.byp; }
+    }
+}
+/* work item: the tokens of the single-block candidates 4 slot .. 4 slot + 3 (their block trials: hv_job_single<8>)  [ref :1434-1435] */
+static HD void hv_w8_single_slot(HvLds &S, HvW8 &W, int slot, HvGLev glev, int lane) {
+    HvLds::Level &L = S.lv[0];
+    const int ii = lane & 15, m0 = 4 * slot + (lane >> 4), ok = m0 < HEVCE_NMODES, t = ok ? m0 : 0;
+    const int kind = hv_scan_kind(8, t);
+    HvGrp G;
+    hv_tokcu(S, W, L, G, t, ok, t, 0, lane);
+    const int cbf = L.tinfo[t][0].cbf, last = L.tinfo[t][0].last, cg_last = last >> 4;
+    const u64 cgsig = L.tinfo[t][0].cgsig;
+    hv_tokhdr(S, W, L, G, t, ok, 8, 3, kind, CX_YCBF + 1, cbf, last, lane);
+    for (int cg = 3; cg >= 0; cg--) {
+        int gy, gx;
+        hv_scan_cg(S, 3, kind, cg, gy, gx);
+        const int cgs = (int)((cgsig >> (gy * 8 + gx)) & 1);
+        const int right = gx < 1 ? (int)((cgsig >> (gy * 8 + gx + 1)) & 1) : 0, below = gy < 1 ? (int)((cgsig >> (gy * 8 + 8 + gx)) & 1) : 0;
+        const int v = (ok && cbf) ? hv_ldc_i16((const short *)(glev + t * 1024 + cg * 16 + ii)) : 0;   /* written by another wavefront of this workgroup: read at the L2 */
+        hv_tokgrp(S, W, L, G, t, ok && cbf, v, 8, kind, cg, cg_last, last, cgs, (below << 1) | right, lane);
+    }
+    if (ok) {
+        W.tok[t][G.cur + ii] = (u8)(HV_PADCV << 1);
+        if (ii == 0) { W.ntok[t] = G.cur; W.nbyp[t] = G.byp; }
+    }
+}
+/* all 70 candidates of the 8x8 CU: results where hv_pw_stage's arg-min expects them (L.tcost / tsse / tregs / tnlog / tctx) */
+static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLev glev, HvGRec grec) {
+    const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
+    HvLds::Level &L = S.lv[0];
+    HvW8 &W = hv_w8(S);
+#ifdef HEVCE_EMU
+    if (tid == 0 && getenv("HEVCE_EMU_W8")) fprintf(stderr, "emu: hv_w8_cu y=%d x=%d\n", cu.y, cu.x);
+#endif
+    if (tid == 0) W.work = 0;
+    if (tid < 5) W.tdone[tid] = 0;
+    hv_level_contexts(S, im, cu);                                /* every candidate's context column = the CU's entry contexts; ends with a barrier */
+    HvPx4 K;
+    hv_px4_consts(S, K, lane);
+#if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
+    unsigned long long w8_ = __builtin_amdgcn_s_memtime();
+#define HV_W8P(i) do { if (lane == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[8 + 3 * hv_uni(wave) + (i)] += n_ - w8_; w8_ = n_; } } while (0)
+#else
+#define HV_W8P(i) do { } while (0)
+#endif
+    for (;;) {
+        /* (wave barriers around the one-lane regions: without them the compiler threaded the `lane == 0` region that ends an item into
+           the one that fetches the next, and the next item ran with lane 0 alone -- seen on the GPU, experiments/README.md round 3) */
+        WAVE_SYNC();
+        int id = 0;
+        if (lane == 0) id = hv_atomic_inc(&W.work);
+        WAVE_SYNC();
+        id = hv_bcast0(id);
+        HV_CHECK_FULL_WAVE(im);
+        HV_W8DBG(im, 1000 + id);
+#if defined(HEVCE_W8DBG) && !defined(HEVCE_EMU)
+        { const unsigned long long am_ = __ballot(1); if (im.trace && lane == (int)__builtin_ctzll(am_) && id < 23) { volatile int *t_ = (volatile int *)im.trace + 64 + 2 * id; t_[0] = (int)(am_ >> 32); t_[1] = (int)am_ ^ (wave << 28); __threadfence_system(); } }
+#endif
+        if (id >= 23) break;
+        if (id < 5) {                                            /* block trials of eight single-block candidates */
+            hv_job_single<8>(wave, lane, q, cu, id, glev, grec);
+            HV_W8DBG(im, 2000 + id);
+            HV_FENCE_RELEASE();
+#ifndef HEVCE_EMU
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the levels have left the compute unit (they are read at the L2) */
+#endif
+            WAVE_SYNC();
+            hv_flag_set(&W.tdone[id], 1);                        /* (every lane stores the same value: no one-lane region here) */
+            HV_W8P(0);
+        } else if (id < 14) { hv_w8_split_slot(S, im, W, K, cu, id - 5, glev, grec, lane); HV_W8DBG(im, 2500 + id); HV_W8P(1); }
+        else {
+            const int slot = id - 14, j0 = (4 * slot) >> 3, j1 = hv_min(4 * slot + 3, 34) >> 3;
+            HV_W8DBG(im, 3000 + id);
+            while (!hv_poll(&W.tdone[j0]) || !hv_poll(&W.tdone[j1])) hv_spin_short();
+            HV_FENCE_ACQUIRE();
+            HV_W8DBG(im, 4000 + id);
+            hv_w8_single_slot(S, W, slot, glev, lane);
+            HV_W8DBG(im, 5000 + id);
+            HV_W8P(2);
+        }
+    }
+    HV_W8DBG(im, 6000);
+    BLOCK_SYNC();
+    HV_W8DBG(im, 7000);
+#if defined(HEVCE_W8DBG) && !defined(HEVCE_EMU)
+    if (im.trace && lane < 9 && wave * 9 + lane < 70) { ((volatile int *)im.trace)[128 + wave * 9 + lane] = W.ntok[wave * 9 + lane]; __threadfence_system(); }
+#endif
+#ifdef HEVCE_EMU
+    if (tid == 0 && getenv("HEVCE_EMU_W8") && cu.y == 0 && cu.x == 0) { fprintf(stderr, "emu ntok/nbyp:"); for (int t_ = 0; t_ < 70; t_++) fprintf(stderr, " (%d,%d)", W.ntok[t_], W.nbyp[t_]); fprintf(stderr, "\n"); }
+#endif
+    /* engines: one lane per candidate */
+    {
+        const int t = wave * 9 + lane;
+        if (lane < 9 && t < 70) {
+            HvFCod c = { S.ent[0].range, S.ent[0].nbits };
+            hv_bengine(S, c, (const HV_LDSP HvChunk *)W.tok[t], W.ntok[t]);
+            const int byp = W.nbyp[t];
+            L.tregs[t] = S.ent[0]; L.tregs[t].range = c.range; L.tregs[t].nbits = c.nbits;
+            L.tnlog[t] = byp; L.tdead[t] = 0; L.tpos[t] = -1;
+            L.tcost[t] = hv_rdcost(q, L.tsse[t], S.ent[0].nbits - c.nbits + byp);
+        }
+    }
+    HV_W8DBG(im, 7500);
+    BLOCK_SYNC();
+    HV_W8DBG(im, 7600);
+}
+
 /* parent workgroup: one stage of a CU's evaluation.  stage 0: block jobs (step 2 / step 3 of the reference's search for this CU,
    [ref :1420-1432, 1455-1468]), 1: context columns + binarisation, 2: the candidates' engines to their end, arg-min, answer. */
 static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, int stage, int lo, int hi, int slot) {   /* candidates [lo, hi), answer to res[slot] */
@@ -3510,7 +3907,8 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
     if (stage == 0) {
         if (tid < HV_TL) { const int mine = tid >= lo && tid < hi; L.tdead[tid] = !mine; L.tpos[tid] = mine ? 0 : -1; L.tlen[tid] = 0; }   /* candidate 70 (NxN) is never this workgroup's */
         if (tid == 0) L.best_cost = HV_I32MAX;
-        if (cu.n == 8) {
+        if (cu.n == 8 && !(im.flags & 8)) hv_w8_cu(S, im, cu, glev, grec);   /* one lane per sample (flag bit 3: the round-2 path below) */
+        else if (cu.n == 8) {
             /* 3 chains (16 modes each, candidates 35..69) + 5 single blocks (8 modes each, candidates 0..34): one job per wavefront,
                and everything that follows for the candidates of that job -- binarisation, engines -- in the same wavefront: nothing
                depends on another wavefront until the arg-min, so there is no barrier in between (the 8x8 answer is on the chain
@@ -3664,6 +4062,7 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
     BLOCK_SYNC();
+    if (serve & 4) { hv_w8_init(S, tid); BLOCK_SYNC(); }
     HevceCluster *C = im.cluster;
     if (im.flags & 4) return;                                    /* test hook: a worker that never answers (as if it had not become resident) */
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
@@ -3752,6 +4151,82 @@ static HD void hv_wr_whole(HvLds &S, const HevceImageDesc &im, int cw) {
         hv_wr_engine(im, cw, 100000);
     }
 }
+/* The writer workgroup of a picture (clusters of five): the CTUs' decision records -> slice data, as soon as the chain workgroup
+   calls them final, reporting what it finds (HevceWrx).  It keeps the state each of its last eight CTUs started from, and goes
+   back when the chain starts a new epoch.  Wavefront 4 does the coding (hv_wr_whole). */
+struct HvWrRing { HevceCoderRegs wr; u8 ctx[HEVCE_NCTXP]; };
+static HD void hv_writer_worker(HvLds &S, const HevceImageDesc &im) {
+    const int tid = hv_tid(), q = im.qpd6;
+    if (tid == 0) { S.trace = nullptr; S.qlut = im.qlut; }
+    BLOCK_SYNC();
+    hv_init_tables(S, q, tid);
+    BLOCK_SYNC();
+    hv_init_sigtab(S, tid);
+    if (tid == 0) { S.cl_fail = 0; S.cl_pick = 0; }
+    BLOCK_SYNC();
+    HevceWrx *X = &im.cluster->wrx;
+    HvWrRing *ring = (HvWrRing *)&S.lv[1];                       /* (no candidates here) */
+    const int nctu = (im.W >> 5) * (im.H >> 5);
+    int c = 0, epoch = 0;
+    if (im.flags & 4) return;                                    /* test hook: a worker that never answers */
+    if (tid == 0) { X->wregs[0] = S.wr; hv_publish_fence(0); hv_st_flag64((unsigned long long *)&X->wdone, 0ull); }
+    for (;;) {
+        if (tid == 0) {
+            const unsigned long long t0 = hv_realtime();
+            int pick;
+            for (;;) {
+                const unsigned long long g = hv_ld_flag64((const unsigned long long *)&X->go);
+                const int e = (int)(g >> 32), cnt = (int)(unsigned)g;
+                if (cnt == 0x7fffffff) { pick = 0; break; }
+                if (e != epoch) { pick = 2; break; }
+                if (cnt > c) { pick = 1; break; }
+                if (hv_realtime() - t0 > HV_CL_TIMEOUT) { pick = 0; im.cluster->error = 4; break; }
+                hv_spin_pause();
+            }
+            hv_acquire_fence(0);
+            S.cl_pick = pick;
+        }
+        BLOCK_SYNC();
+        const int pick = hv_uni(S.cl_pick);
+        BLOCK_SYNC();
+        if (pick == 0) break;
+        if (pick == 2) {                                         /* a new epoch: back to the CTU it restarts at (if this workgroup is past it) */
+            epoch++;
+            const int r = hv_ldc_i32(&X->rst);
+            if (c > r) {
+                if (tid == 0) S.wr = ring[r & 7].wr;
+                if (tid < HEVCE_NCTXP) S.nxn_ctx[tid][HV_TL - 1] = ring[r & 7].ctx[tid];
+                c = r;
+            }
+            BLOCK_SYNC();
+            if (tid == 0) {
+                hv_st_flag64((unsigned long long *)&X->wbad, (unsigned long long)(unsigned)epoch << 32);
+                hv_st_flag64((unsigned long long *)&X->wdone, ((unsigned long long)(unsigned)epoch << 32) | (unsigned)c);
+            }
+            continue;
+        }
+        /* CTU c: remember what it starts from, check the range against the analysis', write it */
+        if (tid == 0) { ring[c & 7].wr = S.wr; S.wr_epb = 0; S.winner = S.wr.range != hv_ldc_i32(&X->crange[c & 7]); }
+        if (tid < HEVCE_NCTXP) ring[c & 7].ctx[tid] = S.nxn_ctx[tid][HV_TL - 1];
+        BLOCK_SYNC();
+        hv_wr_whole(S, im, c);
+        BLOCK_SYNC();
+        if (tid == 0) {
+            const int bad = (S.wr_epb > 0 && !hv_ldc_i32(&X->xflag[c & 7])) || S.winner;
+            X->wregs[(c + 1) & 7] = S.wr;
+            hv_publish_fence(0);
+            if (bad) {
+                const unsigned long long wb = hv_ld_flag64((const unsigned long long *)&X->wbad);
+                if ((int)(wb >> 32) != epoch || (unsigned)wb == 0)
+                    hv_st_flag64((unsigned long long *)&X->wbad, ((unsigned long long)(unsigned)epoch << 32) | (unsigned)(c + 1) | (S.winner ? 0x40000000u : 0u));
+            }
+            hv_st_flag64((unsigned long long *)&X->wdone, ((unsigned long long)(unsigned)epoch << 32) | (unsigned)(c + 1));
+        }
+        c++;
+        BLOCK_SYNC();
+    }
+    (void)nctu;
+}
 /* CTU `ctu` starts from here (the committed coder and contexts, what it reads of its left neighbour and of the CTU row above) */
 static HD void hv_snap_take(HvLds &S, int ctu, int x0, int tid) {
     HvLds::Snap &P = S.snap[ctu & 1];
@@ -3799,12 +4274,17 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     BLOCK_SYNC();
     const int ncx = W >> 5, nctu = ncx * (H >> 5);
     int ctu = 0, redone = -1, n_redo = 0, n_bad = 0;            /* redone: the CTU most recently analysed twice (test hooks fire once) */
+    /* cluster of five: the stream writer is a workgroup of its own (hv_writer_worker), several CTUs behind */
+    const int wrx = im.cluster != nullptr && im.cluster->size >= 5 && !force_exact;
+    HevceWrx *X = wrx ? &im.cluster->wrx : nullptr;
+    int epoch = 0;
+    static_assert(sizeof(HvLds::Snap) == 192, "HevceWrx::snap holds an HvLds::Snap");
     for (;;) {
         const int exact = hv_uni(S.exact);
         const int tail = ctu == nctu;                            /* past the last CTU: only the writer has work left */
         const int cl = im.cluster != nullptr && !exact;          /* the parent workgroup evaluates this CTU's 16x16 / 32x32 CUs */
         const int cl8 = cl && im.cluster->size >= 4;             /* ... and a fourth workgroup the 8x8 CUs' candidates 0..69 */
-        const int wr_on = im.payload && ctu > 0 && hv_uni(S.wr_done) < ctu;   /* the writer does CTU ctu - 1 during this round */
+        const int wr_on = !wrx && im.payload && ctu > 0 && hv_uni(S.wr_done) < ctu;   /* the writer does CTU ctu - 1 during this round */
         const int y0 = (ctu / ncx) * 32, x0 = (ctu % ncx) * 32;
         if (wr_on && tid == 4 * 64) { S.wsnap = S.wr; S.wr_epb = 0; }
         if (wr_on && (tid >> 6) == 4) for (int i = tid & 63; i < HEVCE_NCTXP; i += 64) S.wsnap_ctx[i] = S.nxn_ctx[i][HV_TL - 1];
@@ -3820,7 +4300,20 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                 S.org[p >> 5][p & 31] = im.img[(size_t)yy * (size_t)im.src_stride + xx];
             }
             if (tid < 32) S.rec[1 + tid][HV_RX - 1] = L ? S.rec[1 + tid][HV_RX + 31] : 128;   /* left column = previous CTU's last column */
+            if (wrx && tid == 0) {                               /* never more than six CTUs ahead of the writer: the rings hold eight */
+                const unsigned long long t0 = hv_realtime();
+                for (;;) {
+                    const unsigned long long wd = hv_ld_flag64((const unsigned long long *)&X->wdone);
+                    if ((int)(wd >> 32) == epoch && (int)(unsigned)wd >= ctu - 6) break;
+                    if (hv_realtime() - t0 > HV_CL_TIMEOUT) { S.cl_fail = 1; im.cluster->error = 3; break; }
+                    hv_spin_pause();
+                }
+            }
             BLOCK_SYNC();
+            if (wrx) {                                           /* what this CTU starts from, for a later return to it */
+                if (tid < 48) ((unsigned *)X->snap[ctu & 7])[tid] = ((const HV_LDSP unsigned *)&S.snap[ctu & 1])[tid];
+                if (tid == 64) { X->crange[ctu & 7] = S.com.range; X->xflag[ctu & 7] = exact; }
+            }
             if (tid < 65 && A) {                                 /* row above (x0-1 .. x0+63) from the reconstruction in HBM */
                 const int xx = hv_min(hv_max(x0 + tid - 1, 0), W - 1);
                 S.rec[0][HV_RX - 1 + tid] = im.rcon[(size_t)(y0 - 1) * W + xx];
@@ -3931,6 +4424,65 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
         const int p_wr = p_prev || (wr_on && (S.wr_epb > 0 || bad_wr || (pk_wr && (ctu - 1) % pk_wr == pk_wr - 1 && redone != ctu - 1)));
         const int p_nxn = !tail && !exact && !defer && (S.poison || (pk_nxn && ctu % pk_nxn == pk_nxn - 1 && redone != ctu));
         BLOCK_SYNC();
+        if (wrx) {
+            /* ---- cluster of five: what does the writer workgroup say?  At the end of the picture: wait for it ---- */
+            if (tid == 0) {
+                int roll = p_prev ? ctu - 1 : -1, mism = 0;
+                if (pk_wr && !tail && ctu > 0 && (ctu - 1) % pk_wr == pk_wr - 1 && redone < ctu - 1 - (int)((im.flags >> 24) & 7))
+                    roll = hv_max(ctu - 1 - (int)((im.flags >> 24) & 7), 0);   /* test hook: as if the writer had objected to an earlier CTU (flag bits 24-26: how many further back) */
+                const unsigned long long t0 = hv_realtime();
+                for (;;) {
+                    const unsigned long long wb = hv_ld_flag64((const unsigned long long *)&X->wbad), wd = hv_ld_flag64((const unsigned long long *)&X->wdone);
+                    if ((int)(wb >> 32) == epoch && (unsigned)wb != 0) {
+                        const int r = (int)((unsigned)wb & 0x3fffffffu) - 1;
+                        mism = (int)(((unsigned)wb >> 30) & 1);
+                        roll = (roll < 0 || r < roll) ? r : roll;
+                    }
+                    if (!tail || roll >= 0 || ((int)(wd >> 32) == epoch && (int)(unsigned)wd >= nctu)) break;
+                    if (hv_realtime() - t0 > HV_CL_TIMEOUT) { S.cl_fail = 1; im.cluster->error = 3; break; }
+                    hv_spin_pause();
+                }
+                if (roll >= 0) {                                 /* the writer's registers at that CTU's start: it has to have got there */
+                    for (;;) {
+                        const unsigned long long wd = hv_ld_flag64((const unsigned long long *)&X->wdone);
+                        if (((int)(wd >> 32) == epoch && (int)(unsigned)wd >= roll) || hv_peek(&S.cl_fail)) break;
+                        if (hv_realtime() - t0 > HV_CL_TIMEOUT) { S.cl_fail = 1; im.cluster->error = 3; break; }
+                        hv_spin_pause();
+                    }
+                    hv_acquire_fence(0);
+                }
+                S.cl_pick = roll; S.winner = mism;
+                S.nxv_pend = (defer && !exact && roll < 0) ? 1 : 0; S.poison_prev = 0;
+            }
+            BLOCK_SYNC();
+            const int roll = hv_uni(S.cl_pick);
+            if (hv_uni(S.cl_fail)) break;
+            if (roll >= 0) {
+                /* back to CTU `roll` (up to seven back): the line buffer entries the CTUs since have overwritten, that CTU's start state,
+                   the writer's coder registers there; a new epoch sends the writer back too.  EXACT engines for that one CTU. */
+                n_redo++; n_bad += hv_uni(S.winner);
+                for (int c = hv_min(ctu, nctu - 1); c >= roll; c--)
+                    if (tid < 8) S.line_cu[(((c % ncx) * 32) >> 2) + tid] = (u8)hv_ldc_u8(&((const HvLds::Snap *)X->snap[c & 7])->line_cu[tid]);
+                if (tid < 48) ((HV_LDSP unsigned *)&S.snap[roll & 1])[tid] = hv_ldg_u32((const unsigned *)X->snap[roll & 7] + tid);
+                BLOCK_SYNC();
+                hv_snap_restore(S, roll, (roll % ncx) * 32, tid);
+                BLOCK_SYNC();
+                epoch++;
+                if (tid == 0) {
+                    const HevceCoderRegs *wr_ = &X->wregs[roll & 7];
+                    S.com.range = hv_ldc_i32(&wr_->range); S.com.low = (unsigned)hv_ldc_i32((const int32_t *)&wr_->low); S.com.nbits = hv_ldc_i32(&wr_->nbits);
+                    S.com.nbytes = hv_ldc_i32(&wr_->nbytes); S.com.bufbyte = hv_ldc_i32(&wr_->bufbyte); S.com.zeros = hv_ldc_i32(&wr_->zeros); S.com.nout = hv_ldc_i32(&wr_->nout); S.com.pad = 0;
+                    S.poison = 0;
+                    X->rst = roll;
+                    hv_publish_fence(0);
+                    hv_st_flag64((unsigned long long *)&X->go, ((unsigned long long)(unsigned)epoch << 32) | (unsigned)roll);
+                }
+                hv_set_mode(S, 1, q, tid);
+                redone = roll; ctu = roll;
+                BLOCK_SYNC();
+                continue;
+            }
+        } else {
         if (tid == 0) { S.nxv_pend = (defer && !exact && !p_wr && !p_nxn) ? 1 : 0; S.poison_prev = 0; }
         if (p_wr || p_nxn) {
             /* back to the start of the poisoned CTU (the previous one if the writer or the deferred verification objected), EXACT this
@@ -3950,7 +4502,9 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
             BLOCK_SYNC();
             continue;
         }
+        }
         if (wr_on && tid == 0) S.wr_done = ctu;
+        if (im.cluster && tid == 0 && hv_ldc_i32(&im.cluster->error)) S.cl_fail = 1;   /* a partner workgroup has flagged the cluster (hand-off, HV_CHECK_FULL_WAVE) */
         if (tail) break;
         /* ---- end of CTU: terminate bin, publish reconstruction and line buffers  [ref :1626-1637] ---- */
         if (tid == 0) {
@@ -3968,18 +4522,26 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
         if (tid >= 64 && tid < 72) S.line_cu[(x0 >> 2) + tid - 64] = S.map_cu[8][1 + tid - 64];
         BLOCK_SYNC();
         if (exact && im.payload) {
-            /* an EXACT CTU is written at once: the writer's registers are what the next FAST or EXACT CTU is checked against */
-            hv_wr_whole(S, im, ctu);
-            BLOCK_SYNC();
-            if (tid == 0) {
-                S.wr_done = ctu + 1;
-                const HevceCoderRegs &a = S.com, &b = S.wr;
-                if (ctu != nctu - 1) n_bad += a.range != b.range || a.low != b.low || a.nbits != b.nbits || a.nbytes != b.nbytes || a.bufbyte != b.bufbyte || a.zeros != b.zeros || a.nout != b.nout;
+            /* an EXACT CTU is written at once: the writer's registers are what the next FAST or EXACT CTU is checked against
+               (cluster of five: the writer workgroup does it, and checks the range at the next CTU's start) */
+            if (!wrx) {
+                hv_wr_whole(S, im, ctu);
+                BLOCK_SYNC();
+                if (tid == 0) {
+                    S.wr_done = ctu + 1;
+                    const HevceCoderRegs &a = S.com, &b = S.wr;
+                    if (ctu != nctu - 1) n_bad += a.range != b.range || a.low != b.low || a.nbits != b.nbits || a.nbytes != b.nbytes || a.bufbyte != b.bufbyte || a.zeros != b.zeros || a.nout != b.nout;
+                }
             }
             if (!force_exact) { hv_set_mode(S, 0, q, tid); if (lut4_lds) hv_fill_lut4(S, tid); }
             BLOCK_SYNC();
         }
         ctu++;
+        if (wrx) {                                               /* the CTU's record and samples are final: the writer may have it */
+            hv_publish_fence(0);
+            BLOCK_SYNC();
+            if (tid == 0) hv_st_flag64((unsigned long long *)&X->go, ((unsigned long long)(unsigned)epoch << 32) | (unsigned)ctu);
+        }
     }
     if (im.cluster) {                                            /* the parent workgroup may go home */
         const HvCu none16 = { 0, 0, 16, 4, 1, 0, 0, 0, 0 }, none32 = { 0, 0, 32, 5, 2, 0, 0, 0, 0 };
@@ -3987,6 +4549,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
         hv_cl_send(S, im, none16, nctu, 2);                      /* on both mailboxes: one workgroup may serve both, or one each */
         hv_cl_send(S, im, none32, nctu, 2);
         if (im.cluster->size >= 4) { const HvCu none8 = { 0, 0, 8, 3, 0, 0, 0, 0, 0 }; hv_cl_send(S, im, none8, nctu, 2); }
+        if (im.cluster->size >= 5 && tid == 0) hv_st_flag64((unsigned long long *)&im.cluster->wrx.go, ((unsigned long long)(unsigned)epoch << 32) | 0x7fffffffu);
     }
     if (im.stats && tid == 0) { im.stats[0] = n_redo; im.stats[1] = n_bad + S.cl_fail; }
     if (S.cl_fail && im.payload_len && tid == 0) *im.payload_len = -1;   /* a hand-off timed out: the host encodes the picture again without a cluster */

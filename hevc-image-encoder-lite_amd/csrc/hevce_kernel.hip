@@ -14,7 +14,8 @@ hevce_analyse_kernel(const HevceImageDesc *__restrict__ images, int nimages, int
     if (pic >= nimages) return;
     const HevceImageDesc im = images[pic];
     if (role == 0) hv_analyse_image(HV_S, im);
-    else if (role >= 3) hv_parent_worker(HV_S, im, 4, 0, 70, 2);
+    else if (role == 4) hv_writer_worker(HV_S, im);              /* clusters of five: the stream writer */
+    else if (role == 3) hv_parent_worker(HV_S, im, 4, 0, 70, 2);
     else hv_parent_worker(HV_S, im, cluster == 2 ? 3 : role, 0, 70, 2);
 }
 

@@ -405,7 +405,7 @@ static void ctxs_init(Ctxs *x, int q) {               /* [ref HEVCe.c:727-735, 7
 static inline int64_t coder_bits(const Coder *c) {    /* [ref HEVCe.c:835-837] */
     return 8 * (c->nout + c->nbytes) + 23 - c->nbits;
 }
-/* ---- the product's FAST decision rule, restated for a differential check (tests/test_fast_rule.py) ----
+/* ---- the product's FAST decision rule, restated for a differential check (tests/test_fast_rule.py, tests/tools/fast_rule_sweep.py) ----
    The HIP kernel's trial engines carry the range half of the coder only, so the bit count they cost a candidate with is
    CABAClen minus 8 x (emulation-prevention bytes put during the trial); the product then re-analyses, with exact bit counts,
    every CTU (a) in whose final syntax the stream writer put such a byte or (b) one of whose 64 NxN sub-search winners had one.

@@ -45,7 +45,8 @@ void yield_to_sched() { emu_switch(&fib[emu_cur].sp, sched_sp); }
 
 void fiber_entry() {
     const int role = emu_cur / NT;                               /* cluster mode: workgroup 0 = chain, the others = parents */
-    if (role >= 3) hv_parent_worker(*g_lds[role], *g_im, 4, 0, 70, 2);
+    if (role == 4) hv_writer_worker(*g_lds[role], *g_im);
+    else if (role == 3) hv_parent_worker(*g_lds[role], *g_im, 4, 0, 70, 2);
     else if (role) hv_parent_worker(*g_lds[role], *g_im, g_nwg == 2 ? 3 : role, 0, 70, 2);
     else hv_analyse_image(*g_lds[0], *g_im);
     fib[emu_cur].st = DONE;

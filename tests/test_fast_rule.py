@@ -4,14 +4,14 @@ The HIP kernel decides with bit counts that leave out the emulation-prevention b
 exact counts, the CTUs its stream writer / NxN verification flag (hevce_device.h, hv_fengine_chunk).
 oracle/hevce_oracle.c restates that rule (orc_analyse_fast_rule); here it must reproduce the oracle's records, reconstruction
 and per-CTU coder registers on pictures where such bytes are frequent: constant, faint noise, soft blobs, shallow ramps, one edge.
-tools/fast_rule_sweep.py is the same check at 2 x 10^5 CTUs (profiles/r03_fast_rule_sweep.json)."""
+tests/tools/fast_rule_sweep.py is the same check at 2 x 10^5 CTUs (profiles/r03_fast_rule_sweep.json)."""
 import os
 import sys
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 
 
 def test_fast_rule_matches_the_oracle_on_flat_content():

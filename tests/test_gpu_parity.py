@@ -122,6 +122,35 @@ def test_kodak_sweep_against_manifest(hevce, manifest):
         assert not bad, bad
 
 
+def test_full_size_known_answers(hevce):
+    """BASELINE.json configs[1] and configs[3] at full size against hashes from the REAL reference (oracle/gen_golden_fullsize.py,
+    tests/golden/manifest_fullsize.json): the bench picture (3840x2160 G2-16, 8160 CTUs) and four 1024x1024 tile-pictures of the
+    16384x16384 picture, stream and reconstruction."""
+    import json
+    import hevce_workload as wl
+    with open(os.path.join(os.path.dirname(__file__), "golden", "manifest_fullsize.json")) as f:
+        man = {r["name"]: r for r in json.load(f)}
+    r = man["bench_4k"]
+    img = wl.gen_g2(2160, 3840, 16)
+    with hevce.Job([img.shape], 2) as job:
+        job.upload(0, img)
+        job.run()
+        s, rc = job.stream(0), job.rcon(0)
+    assert len(s) == r["len"] and hashlib.sha256(s).hexdigest() == r["sha256"]
+    assert hashlib.sha256(rc.tobytes()).hexdigest() == r["rcon_sha256"]
+    tiles = [(int(k.split("_")[1][1:]), int(k.split("_")[2][1:]), v) for k, v in man.items() if k.startswith("tile_")]
+    assert len(tiles) >= 2
+    bands = {rr: wl.gen_g2(1024, 16384, 16, seed=0x1234ABCD + 1000 + rr) for rr in sorted({t[0] for t in tiles})}
+    with hevce.Job([(1024, 1024)] * len(tiles), 2) as job:
+        for j, (rr, cc, _) in enumerate(tiles):
+            job.upload_window(j, bands[rr], 0, cc * 1024)
+        job.run()
+        for j, (rr, cc, v) in enumerate(tiles):
+            s = job.stream(j)
+            assert len(s) == v["len"] and hashlib.sha256(s).hexdigest() == v["sha256"], (rr, cc)
+            assert hashlib.sha256(job.rcon(j).tobytes()).hexdigest() == v["rcon_sha256"], (rr, cc)
+
+
 def test_full_size_properties(hevce, orc):
     """BASELINE.json configs[1] shape (3840x2160, pads to 3840x2176 = 8160 CTUs), checked through size-independent
     properties (the CPU oracle would need minutes here): stream == host replay of the device records, every CTU has a

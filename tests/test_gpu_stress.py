@@ -20,4 +20,4 @@ def test_random_pictures_match_oracle_over_repeated_launches(seed, batch):
     res = gpu_stress.sweep(72, seed, 3, batch)
     assert res["mismatches"] == 0 and res["healed_state_mismatches"] == 0, res
     if batch:
-        assert res["workgroups_per_picture"] == [4], res
+        assert res["workgroups_per_picture"] == [5], res

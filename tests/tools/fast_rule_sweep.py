@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential check of the product's FAST decision rule on the CPU (oracle/hevce_oracle.c cost_bits).
+"""TEST INFRASTRUCTURE.  Differential check of the product's FAST decision rule on the CPU (oracle/hevce_oracle.c cost_bits).
 
 The HIP kernel costs trial encodes WITHOUT their emulation-prevention bytes (its FAST engines carry the range half of the coder) and
 re-analyses exactly every CTU the stream writer or the NxN verification flags.  orc_analyse_fast_rule restates that rule on the CPU;
@@ -9,7 +9,7 @@ counter-example to DESIGN.md 4.1.
 
   fast_rule_sweep.py [--ctus N] [--procs P] [--seed S] [--out file.json]"""
 import argparse, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 

@@ -44,7 +44,7 @@ if kind == "phases":
         print("  8x8 worker (cluster >= 4), k cycles per message: wait %.1f, accept %.1f, jobs %.1f, contexts+binarise %.1f, engines+answer %.1f" % tuple(wk[i] / wk[5] / 1e3 for i in range(5)))
         pw = tr[160:224].view(np.uint64).astype(float)[8:32].reshape(8, 3) / wk[5] / 1e3
         for wv in range(8):
-            print("    wavefront %d (%s): block jobs %.1f, binarise %.1f, engines %.1f" % (wv, "TU-split chains, 16 modes" if wv < 3 else "single blocks, 8 modes", pw[wv, 0], pw[wv, 1], pw[wv, 2]))
+            print("    wavefront %d: single-block trial items %.1f, TU-split slots (trials + tokens) %.1f, single-block token slots %.1f   (k cycles per CU; work items are handed out by a counter)" % (wv, pw[wv, 0], pw[wv, 1], pw[wv, 2]))
     if wk[5] > 0:
         hs = p2[5:12] / nctu / 16 / 1e3
         print("  chain workgroup between two 8x8 jobs phases, k cycles per round: NxN report %.1f, wait for the answer %.1f, decision + commit %.1f, samples to HBM %.1f, "
