@@ -86,7 +86,9 @@ typedef struct HevceNxn {      /* analysis workgroup -> 8x8 workgroup, once per 
     uint8_t ctx[104];          /* contexts after it */
     uint8_t rec[64];           /* its reconstruction, 8 x 8 */
 } HevceNxn;
-/* mailboxes: msg / res 0: 16x16, 1: 32x32, msg 2: 8x8 (clusters of four: one message per 16x16 quad); the 8x8 answers alternate between
+/* clusters of six: TWO 8x8 workgroups share the 8x8 CUs' candidates 0..69 (hevce_device.h hv_w8_mine); both read msg[2], the second
+   one answers in res[4] / res[5], and each takes the other's answer into its own decision of the CU.
+   mailboxes: msg / res 0: 16x16, 1: 32x32, msg 2: 8x8 (clusters of four: one message per 16x16 quad); the 8x8 answers alternate between
    res[2] and res[3] and the NxN reports between nxn[0] and nxn[1] (by the parity of the CU's number), so that neither side can
    overwrite what the other is still reading */
 /* clusters of five: the stream writer is a workgroup of its own, several CTUs behind the analysis.  The chain workgroup publishes how many
@@ -105,7 +107,7 @@ typedef struct HevceWrx {
     int32_t  xflag[8];         /* chain : CTU c was analysed EXACT (its emulation-prevention bytes are part of its bit counts) */
     uint8_t  snap[8][192];     /* chain : what CTU c starts from (HvLds::Snap) */
 } HevceWrx;
-typedef struct HevceCluster { HevceMsg msg[3]; HevceRes res[4]; HevceNxn nxn[2]; int32_t error; int32_t size; int32_t pad_[2]; HevceWrx wrx; } HevceCluster;
+typedef struct HevceCluster { HevceMsg msg[3]; HevceRes res[6]; HevceNxn nxn[2]; int32_t error; int32_t size; int32_t pad_[2]; HevceWrx wrx; } HevceCluster;
 
 /* one image of a batch, as the kernel sees it (all pointers are device pointers) */
 typedef struct HevceImageDesc {

@@ -2952,15 +2952,23 @@ static HDN void hv_wr_engine(const HevceImageDesc &im_, int cw, int budget) {
    mode, watches for it during the jobs phase, so that the decision does not begin with a round trip to the L2 for a flag that has
    long been set, and a second one for the cost and the winner: both come with the flag (HevceRes.tag).  Gives up when the chain
    is through. */
+/* clusters of six: two 8x8 workgroups.  Workgroup 0 takes the single-block candidates 0..34 and the TU-split candidates 67..69 (the ninth
+   slot of four modes), workgroup 1 the TU-split candidates 35..66; the better of their two answers -- on equal cost the higher
+   candidate, [ref :1440, 1476] -- is "the 8x8 workgroup's answer" */
+static HD int hv_n8(const HevceImageDesc &im) { return (im.cluster && im.cluster->size >= 6) ? 2 : 1; }
+static HD int hv_w8_owner(int t, int n8) { return (n8 == 2 && t >= 35 && t < 67) ? 1 : 0; }
+static HD int hv_w8_better(int ca, int wa, int cb, int wb) { return cb < ca || (cb == ca && wb > wa); }   /* answer b beats answer a */
 static HD void hv_cl_peek8(HvLds &S, const HevceImageDesc &im, int lane) {
     if (lane) return;
-    const int k = S.cl_ans8 + 1;                                 /* the CU of this round (its decision counts it) */
-    const unsigned long long *tag = (const unsigned long long *)&im.cluster->res[2 + (k & 1)].tag;
+    const int k = S.cl_ans8 + 1, n8 = hv_n8(im);                 /* the CU of this round (its decision counts it) */
+    const unsigned long long *tag0 = (const unsigned long long *)&im.cluster->res[2 + (k & 1)].tag, *tag1 = (const unsigned long long *)&im.cluster->res[4 + (k & 1)].tag;
     for (;;) {
-        const unsigned long long t = hv_ld_flag64(tag);
-        if ((((unsigned)t >> 8) & 0xffffff) == (unsigned)(k & 0xffffff)) {
+        const unsigned long long t0 = hv_ld_flag64(tag0), t1 = n8 == 2 ? hv_ld_flag64(tag1) : t0;
+        if ((((unsigned)t0 >> 8) & 0xffffff) == (unsigned)(k & 0xffffff) && (((unsigned)t1 >> 8) & 0xffffff) == (unsigned)(k & 0xffffff)) {
             hv_acquire_fence(S.cl_light);
-            S.pf.w = (int)((unsigned)t & 0xff); S.pf.cost = (int)(t >> 32); S.pf.k = k;
+            const int w0 = (int)((unsigned)t0 & 0xff), c0 = (int)(t0 >> 32), w1 = (int)((unsigned)t1 & 0xff), c1 = (int)(t1 >> 32);
+            const int b = n8 == 2 && hv_w8_better(c0, w0, c1, w1);
+            S.pf.w = b ? w1 : w0; S.pf.cost = b ? c1 : c0; S.pf.k = k;
             return;
         }
         if (hv_poll(&S.c70_done) >= 5 || hv_peek(&S.cl_fail)) return;
@@ -3444,20 +3452,28 @@ static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu) 
 static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu cu, HevceRecord *rec) {
     const int tid = hv_tid();
     HvLds::Level &L = S.lv[0];
-    const int k = hv_uni(S.cl_ans8) + 1, slot = 2 + (k & 1);     /* this CU's number; counted below */
+    const int k = hv_uni(S.cl_ans8) + 1, n8 = hv_n8(im);         /* this CU's number; counted below */
     const int pf = hv_uni(S.pf.k) == k;                          /* seen during the jobs phase (hv_cl_peek8; barriers since) */
     HV_PROFC(S, -1);
     if (!pf) {
         if (tid == 0) {
             const unsigned long long to = (im.flags & 4) ? 100000ull : HV_CL_TIMEOUT;   /* test hook, see hv_cl_receive */
-            if (!hv_cl_wait(&im.cluster->res[slot].seq, k, &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
+            if (!hv_cl_wait(&im.cluster->res[2 + (k & 1)].seq, k, &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
+            if (n8 == 2 && !hv_cl_wait(&im.cluster->res[4 + (k & 1)].seq, k, &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
         }
         BLOCK_SYNC();
     }
     HV_PROFC(S, 0);
-    const HevceRes *r = &im.cluster->res[slot];
-    const int wa = pf ? hv_min(hv_uni(S.pf.w), 69) : hv_min(hv_max(hv_ldc_i32(&r->winner), 0), 69);
-    const int win70 = L.tcost[70] <= (pf ? hv_uni(S.pf.cost) : hv_ldc_i32(&r->cost));
+    int wa, ca;
+    if (pf) { wa = hv_min(hv_uni(S.pf.w), 69); ca = hv_uni(S.pf.cost); }
+    else {
+        const HevceRes *r0 = &im.cluster->res[2 + (k & 1)], *r1 = &im.cluster->res[4 + (k & 1)];
+        wa = hv_min(hv_max(hv_ldc_i32(&r0->winner), 0), 69); ca = hv_ldc_i32(&r0->cost);
+        if (n8 == 2) { const int wb = hv_min(hv_max(hv_ldc_i32(&r1->winner), 0), 69), cb = hv_ldc_i32(&r1->cost); if (hv_w8_better(ca, wa, cb, wb)) { wa = wb; ca = cb; } }
+    }
+    const int slot = 2 + 2 * hv_w8_owner(wa, n8) + (k & 1);
+    const HevceRes *r = &im.cluster->res[slot];                  /* the answer of the workgroup that candidate came from */
+    const int win70 = L.tcost[70] <= ca;
     const int w = win70 ? 70 : wa;
     HV_GLOBAL u8 *scr = hv_worker8_scratch(im, k);
     HvGLev glev = (HvGLev)scr;
@@ -3466,9 +3482,10 @@ static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu
         S.winner = w;
         if (win70) { S.com = L.tregs[70]; S.com.nbits -= L.tnlog[70]; }
         else { S.com = S.ent[0]; S.com.range = hv_ldc_i32(&r->range); S.com.nbits = hv_ldc_i32(&r->nbits); }
-        const int ok = S.cl_ok | (hv_ldc_i32(&r->pad_[0]) == 1 ? 4 : 0);   /* all of the cluster on this XCD: light hand-offs (hv_cl_receive) */
+        int ok = S.cl_ok | (hv_ldc_i32(&im.cluster->res[2 + (k & 1)].pad_[0]) == 1 ? 4 : 0);   /* all of the cluster on this XCD: light hand-offs (hv_cl_receive) */
+        if (n8 == 2) ok |= hv_ldc_i32(&im.cluster->res[4 + (k & 1)].pad_[0]) == 1 ? 8 : 0;
         S.cl_ok = ok;
-        if ((ok & 7) == 7) S.cl_light = 1;
+        if ((ok & (n8 == 2 ? 15 : 7)) == (n8 == 2 ? 15 : 7)) S.cl_light = 1;
     }
     if (tid >= 64 && tid < 64 + HEVCE_NCTXP) S.com_ctx[tid - 64] = win70 ? L.tctx[tid - 64][70] : (u8)hv_ldc_u8(&r->ctx[tid - 64]);
     const int kindw = w < 35 ? 0 : (w < 70 ? 1 : 2);
@@ -3816,10 +3833,14 @@ static HD void hv_w8_single_slot(HvLds &S, HvW8 &W, int slot, HvGLev glev, int l
     }
 }
 /* all 70 candidates of the 8x8 CU: results where hv_pw_stage's arg-min expects them (L.tcost / tsse / tregs / tnlog / tctx) */
-static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLev glev, HvGRec grec) {
+/* clusters of six: which work items / candidates are 8x8 workgroup g's (items 0..4: single-block trials, 5..13: TU-split slots, 14..22: the
+   single-block candidates' tokens) */
+static HD int hv_w8_mine_item(int id, int g, int n8) { return n8 == 1 || (g == 0 ? (id < 5 || id >= 13) : (id >= 5 && id < 13)); }
+static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLev glev, HvGRec grec, int g8) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
     HvLds::Level &L = S.lv[0];
     HvW8 &W = hv_w8(S);
+    const int n8 = hv_n8(im);
 #ifdef HEVCE_EMU
     if (tid == 0 && getenv("HEVCE_EMU_W8")) fprintf(stderr, "emu: hv_w8_cu y=%d x=%d\n", cu.y, cu.x);
 #endif
@@ -3843,6 +3864,7 @@ static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLe
         WAVE_SYNC();
         id = hv_bcast0(id);
         HV_CHECK_FULL_WAVE(im);
+        if (id < 23 && !hv_w8_mine_item(id, g8, n8)) continue;
         HV_W8DBG(im, 1000 + id);
 #if defined(HEVCE_W8DBG) && !defined(HEVCE_EMU)
         { const unsigned long long am_ = __ballot(1); if (im.trace && lane == (int)__builtin_ctzll(am_) && id < 23) { volatile int *t_ = (volatile int *)im.trace + 64 + 2 * id; t_[0] = (int)(am_ >> 32); t_[1] = (int)am_ ^ (wave << 28); __threadfence_system(); } }
@@ -3882,7 +3904,7 @@ static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLe
     /* engines: one lane per candidate */
     {
         const int t = wave * 9 + lane;
-        if (lane < 9 && t < 70) {
+        if (lane < 9 && t < 70 && hv_w8_owner(t, n8) == g8) {
             HvFCod c = { S.ent[0].range, S.ent[0].nbits };
             hv_bengine(S, c, (const HV_LDSP HvChunk *)W.tok[t], W.ntok[t]);
             const int byp = W.nbyp[t];
@@ -3898,16 +3920,16 @@ static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLe
 
 /* parent workgroup: one stage of a CU's evaluation.  stage 0: block jobs (step 2 / step 3 of the reference's search for this CU,
    [ref :1420-1432, 1455-1468]), 1: context columns + binarisation, 2: the candidates' engines to their end, arg-min, answer. */
-static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, int stage, int lo, int hi, int slot) {   /* candidates [lo, hi), answer to res[slot] */
+static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, int stage, int lo, int hi, int slot, int g8 = 0) {   /* candidates [lo, hi), answer to res[slot]; g8: which 8x8 workgroup */
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6, wv = hv_uni(wave);
     HvLds::Level &L = S.lv[cu.lvl];
     HV_GLOBAL u8 *scr = cu.lvl == 0 ? hv_worker8_scratch(im, hv_uni(S.cl_ans8) + 1) : hv_level_scratch(im, cu.lvl);   /* 8x8: the CU being answered is number cl_ans8 + 1 */
     HvGLev glev = (HvGLev)scr;
     HvGRec grec = (HvGRec)(scr + HV_TL * 1024 * 2);
     if (stage == 0) {
-        if (tid < HV_TL) { const int mine = tid >= lo && tid < hi; L.tdead[tid] = !mine; L.tpos[tid] = mine ? 0 : -1; L.tlen[tid] = 0; }   /* candidate 70 (NxN) is never this workgroup's */
+        if (tid < HV_TL) { const int mine = tid >= lo && tid < hi && (cu.n != 8 || hv_w8_owner(tid, hv_n8(im)) == g8); L.tdead[tid] = !mine; L.tpos[tid] = mine ? 0 : -1; L.tlen[tid] = 0; }   /* candidate 70 (NxN) is never this workgroup's */
         if (tid == 0) L.best_cost = HV_I32MAX;
-        if (cu.n == 8 && !(im.flags & 8)) hv_w8_cu(S, im, cu, glev, grec);   /* one lane per sample (flag bit 3: the round-2 path below) */
+        if (cu.n == 8 && (!(im.flags & 8) || hv_n8(im) == 2)) hv_w8_cu(S, im, cu, glev, grec, g8);   /* one lane per sample (flag bit 3: the round-2 path below) */
         else if (cu.n == 8) {
             /* 3 chains (16 modes each, candidates 35..69) + 5 single blocks (8 modes each, candidates 0..34): one job per wavefront,
                and everything that follows for the candidates of that job -- binarisation, engines -- in the same wavefront: nothing
@@ -3970,7 +3992,7 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
         if (tid == 0) S.winner = bi;                             /* for hv_pw_advance8, behind the barrier below */
         const int w = hv_min(hv_max(hv_bcast0(bi), 0), 69);
         const int k8 = hv_uni(S.cl_ans8) + 1;                     /* 8x8: this is the answer to CU number k8 of the launch */
-        HevceRes *r = &im.cluster->res[cu.lvl == 0 ? 2 + (k8 & 1) : slot];
+        HevceRes *r = &im.cluster->res[cu.lvl == 0 ? 2 + 2 * g8 + (k8 & 1) : slot];
         if (tid == 0) { r->cost = L.tcost[w]; r->winner = w; r->sse = L.tsse[w]; r->range = L.tregs[w].range; r->nbits = L.tregs[w].nbits - L.tnlog[w]; r->pad_[0] = S.cl_light ? 1 : 2; }
         if (tid < HEVCE_NCTXP) r->ctx[tid] = L.tctx[tid][w];
         hv_publish_fence(S.cl_light);                            /* the answer, and the winner's levels / samples in the level scratch */
@@ -4022,25 +4044,35 @@ static HD HvCu hv_pw_accept(HvLds &S, const HevceImageDesc &im, int b) {
    candidate, the NxN one on equal cost (it has the highest index, hv_decide_cu)  [ref :1440, 1476, 1546-1556]; the chain workgroup
    arrives at the same one with the same numbers.  The winner's samples, modes and coder state become the next CU's surroundings and
    entry state  [ref :1364-1373].  Returns 0 when the report did not come (the picture is then flagged).  All threads. */
-static HD int hv_pw_advance8(HvLds &S, const HevceImageDesc &im, const HvCu cu, int m) {
-    const int tid = hv_tid(), k = hv_uni(S.cl_ans8);
+static HD int hv_pw_advance8(HvLds &S, const HevceImageDesc &im, const HvCu cu, int m, int g8) {
+    const int tid = hv_tid(), k = hv_uni(S.cl_ans8), n8 = hv_n8(im);
     HvLds::Level &L = S.lv[0];
     HevceCluster *C = im.cluster;
-    if (tid == 0) { if (!hv_cl_wait(&C->nxn[k & 1].seq, k, &S.cl_fail, S.cl_light)) C->error = 2; }
+    if (tid == 0) {
+        if (!hv_cl_wait(&C->nxn[k & 1].seq, k, &S.cl_fail, S.cl_light)) C->error = 2;
+        if (n8 == 2 && !hv_cl_wait(&C->res[2 + 2 * (g8 ^ 1) + (k & 1)].seq, k, &S.cl_fail, S.cl_light)) C->error = 2;   /* clusters of six: the other 8x8 workgroup's answer */
+    }
     BLOCK_SYNC();
     if (hv_uni(S.cl_fail)) return 0;
     const HevceNxn *r = &C->nxn[k & 1];
-    const int w = hv_min(hv_max(S.winner, 0), 69);
-    const int win70 = hv_ldc_i32(&r->cost) <= L.tcost[w];
+    const HevceRes *po = &C->res[2 + 2 * (g8 ^ 1) + (k & 1)];
+    const int wm = hv_min(hv_max(S.winner, 0), 69), cm = L.tcost[wm];
+    const int wo = n8 == 2 ? hv_min(hv_max(hv_ldc_i32(&po->winner), 0), 69) : 0, co = n8 == 2 ? hv_ldc_i32(&po->cost) : 0;
+    const int other = n8 == 2 && hv_w8_better(cm, wm, co, wo);   /* the partner's candidate is the better one */
+    const int w = other ? wo : wm;
+    const int win70 = hv_ldc_i32(&r->cost) <= (other ? co : cm);
     HvGRec grec = (HvGRec)(hv_worker8_scratch(im, k) + HV_TL * 1024 * 2);
     /* (what the decision reads -- the winner's cost, index -- is not what is written below: no barrier in between) */
-    if (tid < 64) S.rec[cu.y + (tid >> 3) + 1][cu.x + (tid & 7) + HV_RX] = win70 ? (u8)hv_ldc_u8(&r->rec[tid]) : grec[w * 1024 + tid];
+    if (tid < 64) S.rec[cu.y + (tid >> 3) + 1][cu.x + (tid & 7) + HV_RX] = win70 ? (u8)hv_ldc_u8(&r->rec[tid]) : (other ? (u8)hv_ldc_u8((const u8 *)(grec + w * 1024 + tid)) : grec[w * 1024 + tid]);
     if (tid >= 64 && tid < 68) {
         const int s = tid - 64, md = win70 ? (hv_ldc_i32(&r->modes) >> (8 * s)) & 0xff : (w < 35 ? w : w - 35);
         S.q8.pm[2 * (m >> 1) + (s >> 1)][2 * (m & 1) + (s & 1)] = (u8)md;
     }
-    if (tid == 128) { S.ent[0].range = win70 ? hv_ldc_i32(&r->range) : L.tregs[w].range; S.ent[0].nbits = win70 ? hv_ldc_i32(&r->nbits) : L.tregs[w].nbits - L.tnlog[w]; }
-    if (tid >= 256 && tid < 256 + HEVCE_NCTXP) S.ent_ctx[0][tid - 256] = win70 ? (u8)hv_ldc_u8(&r->ctx[tid - 256]) : L.tctx[tid - 256][w];
+    if (tid == 128) {
+        S.ent[0].range = win70 ? hv_ldc_i32(&r->range) : (other ? hv_ldc_i32(&po->range) : L.tregs[w].range);
+        S.ent[0].nbits = win70 ? hv_ldc_i32(&r->nbits) : (other ? hv_ldc_i32(&po->nbits) : L.tregs[w].nbits - L.tnlog[w]);
+    }
+    if (tid >= 256 && tid < 256 + HEVCE_NCTXP) S.ent_ctx[0][tid - 256] = win70 ? (u8)hv_ldc_u8(&r->ctx[tid - 256]) : (other ? (u8)hv_ldc_u8(&po->ctx[tid - 256]) : L.tctx[tid - 256][w]);
     BLOCK_SYNC();
     if (tid == 0) {                                              /* the next CU's neighbour modes  [ref :1369-1373]; read behind the next stage's first barrier */
         const int qy = 2 * ((m + 1) >> 1), qx = 2 * ((m + 1) & 1);
@@ -4052,7 +4084,8 @@ static HD int hv_pw_advance8(HvLds &S, const HevceImageDesc &im, const HvCu cu, 
 /* The parent workgroup of a picture (cluster mode, second workgroup): it answers the chain workgroup's messages until told to
    exit.  16x16 CUs are answered at once (the chain needs them four rounds later); the 32x32 CU of a CTU, whose answer is due
    at the end of the CTU, is worked on stage by stage in between. */
-static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, int lo8, int hi8, int slot8) {   /* serve: bit 0 = the 16x16 mailbox, bit 1 = 32x32, bit 2 = 8x8 (its candidates [lo8, hi8), answered in res[slot8]) */
+static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, int g8 = 0) {   /* serve: bit 0 = the 16x16 mailbox, bit 1 = 32x32, bit 2 = 8x8 (g8: which of the 8x8 workgroups, clusters of six) */
+    const int lo8 = 0, hi8 = 70, slot8 = 2;
     const int tid = hv_tid(), q = im.qpd6;
     if (tid == 0) { S.trace = nullptr; S.qlut = im.qlut; }
     BLOCK_SYNC();
@@ -4114,13 +4147,13 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
                 }
                 for (int st = 0; st < 3; st++) {
                     if (b == 2 && st == 1) continue;             /* an 8x8 CU's stage 0 includes its binarisation and engines */
-                    hv_pw_stage(S, im, cu, st, b == 2 ? lo8 : 0, b == 2 ? hi8 : 70, b == 2 ? slot8 : b);
+                    hv_pw_stage(S, im, cu, st, b == 2 ? lo8 : 0, b == 2 ? hi8 : 70, b == 2 ? slot8 : b, g8);
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
                     if (tid == 0 && b == 2) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[2 + st] += n_ - wt_; wt_ = n_; }
 #endif
                 }
                 if (b == 2 && m8 < 3) {
-                    alive = hv_pw_advance8(S, im, cu, m8);
+                    alive = hv_pw_advance8(S, im, cu, m8, g8);
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
                     if (tid == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[0] += n_ - wt_; wt_ = n_; }
 #endif
@@ -4137,7 +4170,7 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
         }
     }
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
-    if (im.trace && (serve & 4) && slot8 == 2 && tid < 32) ((unsigned long long *)im.trace)[80 + tid] = S.prof2[tid];   /* 8x8 worker: wait, accept, stages 0..2, messages */
+    if (im.trace && (serve & 4) && g8 == 0 && tid < 32) ((unsigned long long *)im.trace)[80 + tid] = S.prof2[tid];   /* 8x8 worker: wait, accept, stages 0..2, messages */
 #endif
 }
 

@@ -196,7 +196,7 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
         /* sizes: 2 = one more workgroup for the 16x16 and 32x32 CUs, 3 = one each, 4 = + one for the 8x8 CUs' candidates 0..69 (and
            the chain workgroup's freed wavefronts help the NxN chain), 5 = candidates 0..34 / 35..69 on a workgroup each -- measured
            no faster than 4 (both halves' critical paths are the same passes), so 5 is only taken when asked for */
-        j->cluster = !j->device_emit ? 1 : (5 * n8 <= cus ? 5 : (4 * n8 <= cus ? 4 : (3 * n8 <= cus ? 3 : (2 * n8 <= cus ? 2 : 1))));   /* 5: + the stream writer on a workgroup of its own */
+        j->cluster = !j->device_emit ? 1 : (6 * n8 <= cus && !getenv("HEVCE_DUMP") ? 6 : 5 * n8 <= cus ? 5 :   /* 6: + a second 8x8 workgroup */ (4 * n8 <= cus ? 4 : (3 * n8 <= cus ? 3 : (2 * n8 <= cus ? 2 : 1))));   /* 5: + the stream writer on a workgroup of its own */
         if (const char *e = getenv("HEVCE_CLUSTER")) { const int mx = atoi(e); if (mx >= 0 && mx < j->cluster) j->cluster = mx < 1 ? 1 : mx; }
     }
     if (getenv("HEVCE_DUMP")) {

@@ -15,8 +15,9 @@ hevce_analyse_kernel(const HevceImageDesc *__restrict__ images, int nimages, int
     const HevceImageDesc im = images[pic];
     if (role == 0) hv_analyse_image(HV_S, im);
     else if (role == 4) hv_writer_worker(HV_S, im);              /* clusters of five: the stream writer */
-    else if (role == 3) hv_parent_worker(HV_S, im, 4, 0, 70, 2);
-    else hv_parent_worker(HV_S, im, cluster == 2 ? 3 : role, 0, 70, 2);
+    else if (role == 3) hv_parent_worker(HV_S, im, 4, 0);
+    else if (role == 5) hv_parent_worker(HV_S, im, 4, 1);       /* clusters of six: the second 8x8 workgroup */
+    else hv_parent_worker(HV_S, im, cluster == 2 ? 3 : role);
 }
 
 /* host-side launcher used by hevce_host.cpp: grid = images of the batch (times the cluster size) */

@@ -6,10 +6,10 @@
 
 int emu_cur = 0;
 HvLds *emu_lds_ptr = nullptr;
-int emu_stage[40][64];
+int emu_stage[48][64];
 
 namespace {
-enum { NT = HV_NTHREADS, NWG = 5, STACK = 256 * 1024 };
+enum { NT = HV_NTHREADS, NWG = 6, STACK = 256 * 1024 };
 enum State { RUN, WAIT_WAVE, WAIT_BLOCK, DONE };
 struct Fiber { void *sp; State st; char *stack; };
 Fiber fib[NWG * NT];
@@ -46,8 +46,9 @@ void yield_to_sched() { emu_switch(&fib[emu_cur].sp, sched_sp); }
 void fiber_entry() {
     const int role = emu_cur / NT;                               /* cluster mode: workgroup 0 = chain, the others = parents */
     if (role == 4) hv_writer_worker(*g_lds[role], *g_im);
-    else if (role == 3) hv_parent_worker(*g_lds[role], *g_im, 4, 0, 70, 2);
-    else if (role) hv_parent_worker(*g_lds[role], *g_im, g_nwg == 2 ? 3 : role, 0, 70, 2);
+    else if (role == 3) hv_parent_worker(*g_lds[role], *g_im, 4, 0);
+    else if (role == 5) hv_parent_worker(*g_lds[role], *g_im, 4, 1);
+    else if (role) hv_parent_worker(*g_lds[role], *g_im, g_nwg == 2 ? 3 : role);
     else hv_analyse_image(*g_lds[0], *g_im);
     fib[emu_cur].st = DONE;
     ndone++;
@@ -133,7 +134,7 @@ int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, 
                 progress = true;
             }
         if (!progress) {
-            fprintf(stderr, "emu: deadlock (divergent synchronisation): block_wait=%d %d %d %d done=%d waves:", block_wait[0], block_wait[1], block_wait[2], block_wait[3] + 1000 * block_wait[4], ndone);
+            fprintf(stderr, "emu: deadlock (divergent synchronisation): block_wait=%d %d %d %d done=%d waves:", block_wait[0], block_wait[1], block_wait[2], block_wait[3] + 1000 * block_wait[4] + 1000000 * block_wait[5], ndone);
             for (int w = 0; w < nwg * 8; w++) fprintf(stderr, " %d", wave_wait[w]);
             fprintf(stderr, "\n");
             rc = -1;

@@ -59,7 +59,7 @@ def test_emulated_kernel_reanalysis_paths(path, flags):
     assert (redo > 0) == (flags != 1)
 
 
-@pytest.mark.parametrize("nwg", [2, 3, 4, 5])
+@pytest.mark.parametrize("nwg", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("flags", [0, 2 << 8, 3 << 16, (3 << 16) | (4 << 24)], ids=["fast", "nxn2", "wr3", "wr3-back5"])
 @pytest.mark.parametrize("path", MODE_CASES, ids=lambda p: os.path.basename(p)[6:-4])
 def test_emulated_cluster_of_workgroups(path, flags, nwg):
