@@ -73,6 +73,8 @@ def lib():
         L.hevce_job_download_rcon.argtypes = [C.c_void_p, C.c_int, _u8p]
         L.hevce_job_device_rcon.restype = C.c_void_p
         L.hevce_job_device_rcon.argtypes = [C.c_void_p, C.c_int]
+        L.hevce_job_device_payload.restype = C.c_void_p
+        L.hevce_job_device_payload.argtypes = [C.c_void_p, C.c_int, _i32p]
         L.hevce_job_device_records.restype = C.c_void_p
         L.hevce_job_device_records.argtypes = [C.c_void_p, C.c_int]
         L.hevce_job_download_records.argtypes = [C.c_void_p, C.c_int, _u8p, _i32p]
@@ -152,6 +154,7 @@ class Job:
         if not self._h:
             raise HevceError(f"hevce_job_create failed: {lib().hevce_last_error().decode()}")
         self._keep = {}
+        self._up = {}
 
     def close(self):
         if getattr(self, "_h", None):
@@ -169,6 +172,9 @@ class Job:
     def upload(self, i, img):
         img = np.ascontiguousarray(img, np.uint8)
         assert img.shape == self.sizes[i]
+        # the copy is asynchronous on the job's stream; a pinned source is read by DMA after this call returns (include/hevce_mi355x.h,
+        # hevce_job_upload): keep the array until the picture is replaced or the job closed
+        self._up[i] = img
         _check(lib().hevce_job_upload(self._h, i, _p(img)), "hevce_job_upload")
 
     def set_device_image(self, i, ptr, keepalive=None):
@@ -182,6 +188,7 @@ class Job:
         h, w = self.sizes[i]
         assert 0 <= y0 and 0 <= x0 and y0 + h <= picture.shape[0] and x0 + w <= picture.shape[1]
         origin = picture.ctypes.data + y0 * picture.shape[1] + x0
+        self._up[i] = picture                                    # (see upload)
         _check(lib().hevce_job_upload_window(self._h, i, C.c_void_p(origin), picture.shape[1]), "hevce_job_upload_window")
 
     def set_device_window(self, i, origin_ptr, stride, keepalive=None):
@@ -259,6 +266,13 @@ class Job:
 
     def device_rcon_ptr(self, i):
         return lib().hevce_job_device_rcon(self._h, i)
+
+    def device_payload(self, i):
+        """(device pointer, length) of image i's slice data in HBM -- the stream without its parameter-set header -- after a finished
+        launch; (None, 0) when there is none"""
+        n = C.c_int(0)
+        p = lib().hevce_job_device_payload(self._h, int(i), C.byref(n))
+        return (int(p), int(n.value)) if p else (None, 0)
 
     def timings(self):
         k, d, w = C.c_float(), C.c_float(), C.c_float()

@@ -107,7 +107,11 @@ typedef struct HevceWrx {
     int32_t  xflag[8];         /* chain : CTU c was analysed EXACT (its emulation-prevention bytes are part of its bit counts) */
     uint8_t  snap[8][192];     /* chain : what CTU c starts from (HvLds::Snap) */
 } HevceWrx;
-typedef struct HevceCluster { HevceMsg msg[3]; HevceRes res[6]; HevceNxn nxn[2]; int32_t error; int32_t size; int32_t pad_[2]; HevceWrx wrx; } HevceCluster;
+/* alive[r]: workgroup r of the cluster has started (it is RESIDENT: its hand-offs will be answered).  The chain workgroup waits for all of
+   them before the first CTU, a few milliseconds at most (HV_CL_ALIVE_TIMEOUT): a cluster whose workgroups the device has not placed
+   side by side -- other kernels hold the compute units -- is given up at once and the host encodes the picture without clusters.
+   error: 1-4 a hand-off timed out, 5 a wavefront ran with lanes missing, 6 a workgroup of the cluster was not resident */
+typedef struct HevceCluster { HevceMsg msg[3]; HevceRes res[6]; HevceNxn nxn[2]; int32_t error; int32_t size; int32_t pad_[2]; int32_t alive[8]; HevceWrx wrx; } HevceCluster;
 
 /* one image of a batch, as the kernel sees it (all pointers are device pointers) */
 typedef struct HevceImageDesc {

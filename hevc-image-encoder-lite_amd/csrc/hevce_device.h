@@ -125,7 +125,12 @@ template <typename T> static HD T *hv_uni_ptr(T *p) {
    invalidate, what the memory model asks for between arbitrary workgroups.  LIGHT, when both workgroups are known to sit on the
    SAME XCD (they then share the L2, and the L1s are write-through): the producer only waits until its stores have left the
    compute unit, the consumer reads the payload with L1-bypassing loads (hv_ldg_*); no L2 maintenance at all.  Which one applies
-   is decided at run time from the XCC_ID hardware register of the workgroups involved (HvLds::cl_light). */
+   is decided at run time from the XCC_ID hardware register of the workgroups involved (HvLds::cl_light).
+   What the LIGHT flavour ASSUMES of gfx950, beyond the HSA memory model: (1) workgroups that report the same XCC_ID are served by the
+   same L2, which is the point of coherence for them; (2) a vector store has reached that L2 when `s_waitcnt vmcnt(0)` lets the wave go on
+   (the L1 is write-through, stores are acknowledged by the L2); (3) loads marked system-coherent / L1-bypassing (hv_ldg_*, hv_ldc_*: sc1
+   sc0 loads) are served by the L2 and never by a stale L1 line.  The HEAVY flavour assumes none of this; im.flags bit 4 (HEVCE_FLAGS=16)
+   forces it for every hand-off, so that the two can be told apart on the device (tests/test_gpu_parity.py runs both). */
 static HD void hv_publish_fence(int light) {
     if (light) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -2124,10 +2129,19 @@ static HD void hv_rengine(const HvLds &S, HvFCod &c, ChunkPtr sp, int n) {
 /* one pass: the block trials and the binarisation of the four modes 4 * slot .. 4 * slot + 3 (whole wavefront) */
 static HD void hv_nxn_pass(HvLds &S, const HvPx4 &K, const HV_LDSP u16 *lut4, int q, int ty, int tx, int slot, int lane) {
     const int m = 4 * slot + (lane >> 4), ok = m < HEVCE_NMODES;
+#if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
+    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
     hv_tu4_px(S, K, lut4, q, ty, tx, m, ok, lane);
     WAVE_SYNC();
+#if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
+    const unsigned long long t1_ = __builtin_amdgcn_s_memtime();
+#endif
     hv_tok4_px(S, m, ok, lane);
     WAVE_SYNC();
+#if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
+    if (slot == 2 && lane == 0) { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); S.prof2[13] += t1_ - t0_; S.prof2[14] += t2_ - t1_; S.prof2[15] += 1; }   /* (one helper's first pass) */
+#endif
 }
 
 /* a helper wavefront of the NxN chain (cluster of four): for each of the CU's four 4x4 blocks, when the chain has laid out the
@@ -3074,7 +3088,11 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
 
 /* cluster mode (described further down): mailbox numbering and the bounded wait */
 #define HV_CL_BOX(lvl) (((lvl) + 2) % 3)                    /* mailbox of a CU level: 16x16 -> 0, 32x32 -> 1, 8x8 -> 2 */
-#define HV_CL_TIMEOUT 3000000000ull                          /* 30 s of the 100 MHz clock */
+/* Waits between workgroups that are all RESIDENT (the chain workgroup has seen every alive word, hv_cl_alive) end when the partner has
+   done its work -- tens of milliseconds at the very most (a CTU analysed again with the EXACT engines) -- so the hand-off timeout is a
+   backstop against a wedged partner, not the detector of a cluster that was never placed: that one is the alive wait, 20 ms. */
+#define HV_CL_TIMEOUT 300000000ull                           /* 3 s of the 100 MHz clock */
+#define HV_CL_ALIVE_TIMEOUT 2000000ull                       /* 20 ms */
 static HD int hv_cl_wait(const int *seq, int want, int *fail, int light, unsigned long long timeout = HV_CL_TIMEOUT) {   /* one thread */
     const unsigned long long t0 = hv_realtime();
     for (;;) {
@@ -3118,7 +3136,7 @@ static HD void hv_decide_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, i
             L.tregs[wa] = S.ent[cu.lvl]; L.tregs[wa].range = hv_ldc_i32(&r->range); L.tregs[wa].nbits = hv_ldc_i32(&r->nbits); L.tnlog[wa] = 0;
             const int ok = S.cl_ok | (hv_ldc_i32(&r->pad_[0]) == 1 ? 1 << b : 0);
             S.cl_ok = ok;
-            if ((ok & (im.cluster->size <= 3 ? 3 : 7)) == (im.cluster->size <= 3 ? 3 : 7)) S.cl_light = 1;
+            if ((ok & (im.cluster->size <= 3 ? 3 : 7)) == (im.cluster->size <= 3 ? 3 : 7) && !(im.flags & 16)) S.cl_light = 1;
         }
         if (wl >= 0 && tid >= 64 && tid < 64 + HEVCE_NCTXP) L.tctx[tid - 64][wa] = (u8)hv_ldc_u8(&r->ctx[tid - 64]);
         BLOCK_SYNC();
@@ -3440,7 +3458,7 @@ static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu) 
         int ok = S.cl_ok | (hv_ldc_i32(&r->pad_[0]) == 1 ? 1 << b : 0);
         S.cl_ok = ok;
         const int need = size <= 3 ? 3 : 7;
-        if ((ok & need) == need) S.cl_light = 1;
+        if ((ok & need) == need && !(im.flags & 16)) S.cl_light = 1;
     }
     if (tid < HEVCE_NCTXP) L.tctx[tid][w] = (u8)hv_ldc_u8(&r->ctx[tid]);
     BLOCK_SYNC();
@@ -3485,7 +3503,7 @@ static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu
         int ok = S.cl_ok | (hv_ldc_i32(&im.cluster->res[2 + (k & 1)].pad_[0]) == 1 ? 4 : 0);   /* all of the cluster on this XCD: light hand-offs (hv_cl_receive) */
         if (n8 == 2) ok |= hv_ldc_i32(&im.cluster->res[4 + (k & 1)].pad_[0]) == 1 ? 8 : 0;
         S.cl_ok = ok;
-        if ((ok & (n8 == 2 ? 15 : 7)) == (n8 == 2 ? 15 : 7)) S.cl_light = 1;
+        if ((ok & (n8 == 2 ? 15 : 7)) == (n8 == 2 ? 15 : 7) && !(im.flags & 16)) S.cl_light = 1;
     }
     if (tid >= 64 && tid < 64 + HEVCE_NCTXP) S.com_ctx[tid - 64] = win70 ? L.tctx[tid - 64][70] : (u8)hv_ldc_u8(&r->ctx[tid - 64]);
     const int kindw = w < 35 ? 0 : (w < 70 ? 1 : 2);
@@ -3852,8 +3870,11 @@ static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLe
 #if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
     unsigned long long w8_ = __builtin_amdgcn_s_memtime();
 #define HV_W8P(i) do { if (lane == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[8 + 3 * hv_uni(wave) + (i)] += n_ - w8_; w8_ = n_; } } while (0)
+#define HV_W8Q(i) do { if (tid == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[i] += n_ - w8q_; w8q_ = n_; } } while (0)
+    unsigned long long w8q_ = w8_;
 #else
 #define HV_W8P(i) do { } while (0)
+#define HV_W8Q(i) do { } while (0)
 #endif
     for (;;) {
         /* (wave barriers around the one-lane regions: without them the compiler threaded the `lane == 0` region that ends an item into
@@ -3894,6 +3915,7 @@ static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLe
     }
     HV_W8DBG(im, 6000);
     BLOCK_SYNC();
+    HV_W8Q(6);                                                   /* the work items, to the last wavefront's end */
     HV_W8DBG(im, 7000);
 #if defined(HEVCE_W8DBG) && !defined(HEVCE_EMU)
     if (im.trace && lane < 9 && wave * 9 + lane < 70) { ((volatile int *)im.trace)[128 + wave * 9 + lane] = W.ntok[wave * 9 + lane]; __threadfence_system(); }
@@ -3915,6 +3937,7 @@ static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLe
     }
     HV_W8DBG(im, 7500);
     BLOCK_SYNC();
+    HV_W8Q(7);                                                   /* the candidates' engines */
     HV_W8DBG(im, 7600);
 }
 
@@ -4020,7 +4043,7 @@ static HD HvCu hv_pw_accept(HvLds &S, const HevceImageDesc &im, int b) {
     if (tid == 0) {
         S.ent[lvl].range = hv_ldc_i32(&m->range); S.ent[lvl].low = 0; S.ent[lvl].nbits = hv_ldc_i32(&m->nbits); S.ent[lvl].nbytes = 0; S.ent[lvl].bufbyte = 0; S.ent[lvl].zeros = 0; S.ent[lvl].nout = 0; S.ent[lvl].pad = 0;
         L.split_inc = hv_ldc_i32(&m->split_inc); L.ml = hv_ldc_i32(&m->ml); L.ma = hv_ldc_i32(&m->ma);
-        S.cl_light = hv_ldc_i32(&m->pad_) == hv_xcc_id();          /* the chain workgroup sits on this XCD: light hand-offs from now on */
+        S.cl_light = hv_ldc_i32(&m->pad_) == hv_xcc_id() && !(im.flags & 16);   /* the chain workgroup sits on this XCD: light hand-offs from now on (flag bit 4: never) */
         if (b == 2) {                                            /* the quad this 8x8 CU opens */
             S.q8.y = cu.y; S.q8.x = cu.x; S.q8.ctu = ctu; S.q8.ml0 = L.ml; S.q8.ma0 = L.ma; S.q8.ml2 = hv_ldc_i32(&m->ml2); S.q8.ma2 = hv_ldc_i32(&m->ma2);
             S.q8.L = hv_ldc_i32(&m->qL); S.q8.LB = hv_ldc_i32(&m->qLB); S.q8.A = hv_ldc_i32(&m->qA); S.q8.AR = hv_ldc_i32(&m->qAR);
@@ -4098,6 +4121,7 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
     if (serve & 4) { hv_w8_init(S, tid); BLOCK_SYNC(); }
     HevceCluster *C = im.cluster;
     if (im.flags & 4) return;                                    /* test hook: a worker that never answers (as if it had not become resident) */
+    if (tid == 0) hv_st_flag(&C->alive[(serve & 4) ? 3 + 2 * g8 : (serve == 2 ? 2 : 1)], 1);   /* this workgroup is resident (hv_cl_alive) */
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     if (tid < 32) S.prof2[tid] = 0;
     unsigned long long wt_ = __builtin_amdgcn_s_memtime();
@@ -4170,7 +4194,7 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
         }
     }
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
-    if (im.trace && (serve & 4) && g8 == 0 && tid < 32) ((unsigned long long *)im.trace)[80 + tid] = S.prof2[tid];   /* 8x8 worker: wait, accept, stages 0..2, messages */
+    if (im.trace && (serve & 4) && g8 == ((im.flags >> 5) & 1) && tid < 32) ((unsigned long long *)im.trace)[80 + tid] = S.prof2[tid];   /* 8x8 worker: wait, accept, stages 0..2, messages */
 #endif
 }
 
@@ -4202,8 +4226,16 @@ static HD void hv_writer_worker(HvLds &S, const HevceImageDesc &im) {
     const int nctu = (im.W >> 5) * (im.H >> 5);
     int c = 0, epoch = 0;
     if (im.flags & 4) return;                                    /* test hook: a worker that never answers */
+    if (tid == 0) hv_st_flag(&im.cluster->alive[4], 1);          /* this workgroup is resident (hv_cl_alive) */
     if (tid == 0) { X->wregs[0] = S.wr; hv_publish_fence(0); hv_st_flag64((unsigned long long *)&X->wdone, 0ull); }
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+    unsigned long long wp_wait = 0, wp_busy = 0, wp_n = 0, wp_t = __builtin_amdgcn_s_memtime();
+#define HV_WRP(acc) do { if (tid == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc += n_ - wp_t; wp_t = n_; } } while (0)
+#else
+#define HV_WRP(acc) do { } while (0)
+#endif
     for (;;) {
+        HV_WRP(wp_busy);
         if (tid == 0) {
             const unsigned long long t0 = hv_realtime();
             int pick;
@@ -4219,6 +4251,7 @@ static HD void hv_writer_worker(HvLds &S, const HevceImageDesc &im) {
             hv_acquire_fence(0);
             S.cl_pick = pick;
         }
+        HV_WRP(wp_wait);
         BLOCK_SYNC();
         const int pick = hv_uni(S.cl_pick);
         BLOCK_SYNC();
@@ -4257,7 +4290,13 @@ static HD void hv_writer_worker(HvLds &S, const HevceImageDesc &im) {
         }
         c++;
         BLOCK_SYNC();
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+        wp_n++;
+#endif
     }
+#if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
+    if (im.trace && tid == 0) { ((unsigned long long *)im.trace)[57] = wp_wait; ((unsigned long long *)im.trace)[58] = wp_busy; ((unsigned long long *)im.trace)[59] = wp_n; }
+#endif
     (void)nctu;
 }
 /* CTU `ctu` starts from here (the committed coder and contexts, what it reads of its left neighbour and of the CTU row above) */
@@ -4276,6 +4315,19 @@ static HD void hv_snap_restore(HvLds &S, int ctu, int x0, int tid) {
     if (tid >= 192 && tid < 224) S.rec[1 + tid - 192][HV_RX + 31] = P.rec_col[tid - 192];
 }
 
+/* chain workgroup, before the first CTU: every other workgroup of the cluster has started (HevceCluster.alive).  One thread; returns 0
+   and flags the cluster when one has not shown up in time */
+static HD int hv_cl_alive(const HevceImageDesc &im) {
+    HevceCluster *C = im.cluster;
+    const unsigned long long t0 = hv_realtime(), to = (im.flags & 4) ? 100000ull : HV_CL_ALIVE_TIMEOUT;   /* test hook: 1 ms */
+    for (;;) {
+        int all = 1;
+        for (int r = 1; r < C->size; r++) all &= hv_ld_flag(&C->alive[r]) != 0;
+        if (all) return 1;
+        if (hv_realtime() - t0 > to) { C->error = 6; return 0; }
+        hv_spin_pause();
+    }
+}
 /* The picture: CTUs in raster order, analysed with the FAST engines while the writer (one CTU behind) produces the bytes.
    A CTU whose decisions the FAST bit counts cannot vouch for -- the writer put an emulation-prevention byte while encoding it,
    or one of its NxN winners would have had one -- is POISONED: the workgroup goes back to that CTU's start, analyses it with
@@ -4312,7 +4364,11 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     HevceWrx *X = wrx ? &im.cluster->wrx : nullptr;
     int epoch = 0;
     static_assert(sizeof(HvLds::Snap) == 192, "HevceWrx::snap holds an HvLds::Snap");
-    for (;;) {
+    if (im.cluster) {                                            /* all of the cluster is resident, or the picture is given back to the host at once */
+        if (tid == 0 && !hv_cl_alive(im)) S.cl_fail = 1;
+        BLOCK_SYNC();
+    }
+    while (!hv_uni(S.cl_fail)) {
         const int exact = hv_uni(S.exact);
         const int tail = ctu == nctu;                            /* past the last CTU: only the writer has work left */
         const int cl = im.cluster != nullptr && !exact;          /* the parent workgroup evaluates this CTU's 16x16 / 32x32 CUs */
@@ -4539,6 +4595,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
         if (wr_on && tid == 0) S.wr_done = ctu;
         if (im.cluster && tid == 0 && hv_ldc_i32(&im.cluster->error)) S.cl_fail = 1;   /* a partner workgroup has flagged the cluster (hand-off, HV_CHECK_FULL_WAVE) */
         if (tail) break;
+        if (im.cluster) { BLOCK_SYNC(); if (hv_uni(S.cl_fail)) break; }   /* the picture is lost to this launch: no point in walking the rest of it */
         /* ---- end of CTU: terminate bin, publish reconstruction and line buffers  [ref :1626-1637] ---- */
         if (tid == 0) {
             hv_commit_terminate(S, ctu == nctu - 1);

@@ -2,9 +2,12 @@
  * hevce_host.cpp -- C-ABI shim and HIP plumbing around the analysis kernel (include/hevce_mi355x.h).
  *
  * One job = a batch of independent images.  All of a job's device memory is one slab in HBM:
- *   per image: source luma | padded reconstruction | decision records | per-CTU coder state | trial scratch
- * and one pinned host slab receives the records.  The kernel runs one workgroup per image; the host then
- * replays the records into .h265 bytes (hevce_writer.cpp), one host thread per image.
+ *   per image: source luma | padded reconstruction | decision records | per-CTU coder state | trial scratch | slice data and its
+ *   length | re-analysis statistics | the stream writer's token slots | the cluster's mailboxes
+ * The kernel (hevce_kernel.hip) analyses a picture AND writes its slice data: one workgroup per picture, or -- when the device has the
+ * compute units to spare -- a cluster of up to six workgroups per picture (hevce_device.h: chain, 16x16, 32x32, two 8x8 workgroups,
+ * stream writer).  The host puts the VPS/SPS/PPS/slice header in front and fetches exactly the bytes of each stream.  Only with
+ * HEVCE_HOST_WRITER=1 (diagnostics) do the decision records travel and are replayed into bytes on the host (hevce_writer.cpp).
  *
  * HEVCImageEncoder() keeps the reference's signature (reference src/HEVCe.h:5-12).  The reference cannot fail;
  * this implementation can (no device): it then returns a negative length and reports on stderr -- it never
@@ -89,6 +92,28 @@ const uint16_t *qlut_device(int device, int q) {
     return g_qlut_dev[device] + size_t(q) * kQlutPerQ;
 }
 
+/* ---- compute units claimed by launches in flight, per device.  A cluster's workgroups wait for each other, so all of them have to be
+   resident at once: a launch takes the largest cluster size that fits beside what this process already has on the device, and
+   gives its units back when it has finished.  (Other processes' kernels are not seen here: the kernel's own alive check, hevce_device.h
+   hv_cl_alive, catches a cluster that was not placed and the launch is repeated without clusters.)  HEVCE_CU_BUDGET=0 switches the
+   accounting off (tests of that check) ---- */
+std::mutex g_cu_mutex;
+int g_cu_claimed[64] = {};
+int cu_claim(int device, int want_per_role, int max_cluster, int cus, int *claimed) {
+    static const bool on = !(getenv("HEVCE_CU_BUDGET") && atoi(getenv("HEVCE_CU_BUDGET")) == 0);
+    std::lock_guard<std::mutex> lock(g_cu_mutex);
+    const int held = (on && device >= 0 && device < 64) ? g_cu_claimed[device] : 0;
+    int c = max_cluster;
+    while (c > 1 && held + c * want_per_role > cus) c--;
+    *claimed = c > 1 ? c * want_per_role : (want_per_role < cus ? want_per_role : cus);
+    if (on && device >= 0 && device < 64) g_cu_claimed[device] += *claimed;
+    return c;
+}
+void cu_release(int device, int claimed) {
+    std::lock_guard<std::mutex> lock(g_cu_mutex);
+    if (device >= 0 && device < 64) { g_cu_claimed[device] -= claimed; if (g_cu_claimed[device] < 0) g_cu_claimed[device] = 0; }
+}
+
 inline int pad32(int v) { return ((v < HEVCE_MAXDIM ? v : HEVCE_MAXDIM) + 31) / 32 * 32; }
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
@@ -130,7 +155,11 @@ struct hevce_job {
     bool device_emit = true;         /* the kernel emits the slice data itself; HEVCE_HOST_WRITER=1: replay the records on the host instead */
     int flags = 0;                   /* HevceImageDesc.flags (tests: HEVCE_FLAGS) */
     int cluster_fallbacks = 0;       /* launches repeated without clusters after a hand-off timed out */
-    int cluster = 1;                 /* workgroups per picture (hevce_device.h cluster mode): as many (<= 3) as fit the device side by side */
+    int cluster = 1;                 /* workgroups per picture (hevce_device.h cluster mode) at most: what the whole device has room for */
+    int cluster_now = 1;             /* ... of the launch in flight / the last one: what was free beside this process's other launches (cu_claim) */
+    bool single_once = false;        /* the next launch runs without clusters (the repeat of one whose cluster was not placed) */
+    int cus = 0, cu_claimed = 0;     /* the device's compute units; those this job's launch in flight holds */
+    HevceCluster *h_cluster_init = nullptr;   /* pinned: the zeroed mailboxes every launch starts from */
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     float kernel_ms = 0, d2h_ms = 0, writer_ms = 0;
@@ -192,12 +221,20 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
         hipDeviceProp_t prop;
         int cus = 0;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+        j->cus = cus;
         const int n8 = (n + 7) & ~7;                             /* the grid is padded to eight pictures per role (one cluster = one XCD, hevce_kernel.hip) */
         /* sizes: 2 = one more workgroup for the 16x16 and 32x32 CUs, 3 = one each, 4 = + one for the 8x8 CUs' candidates 0..69 (and
-           the chain workgroup's freed wavefronts help the NxN chain), 5 = candidates 0..34 / 35..69 on a workgroup each -- measured
-           no faster than 4 (both halves' critical paths are the same passes), so 5 is only taken when asked for */
-        j->cluster = !j->device_emit ? 1 : (6 * n8 <= cus && !getenv("HEVCE_DUMP") ? 6 : 5 * n8 <= cus ? 5 :   /* 6: + a second 8x8 workgroup */ (4 * n8 <= cus ? 4 : (3 * n8 <= cus ? 3 : (2 * n8 <= cus ? 2 : 1))));   /* 5: + the stream writer on a workgroup of its own */
+           the chain workgroup's freed wavefronts help the NxN chain), 5 = + the stream writer on a workgroup of its own, 6 = + a second
+           8x8 workgroup (the candidates 0..69 shared between the two).  The per-candidate dump (HEVCE_DUMP) knows clusters up to 5 */
+        const int top = getenv("HEVCE_DUMP") ? 5 : 6;
+        j->cluster = 1;
+        if (j->device_emit) for (int c = top; c >= 2; c--) if (c * n8 <= cus) { j->cluster = c; break; }
         if (const char *e = getenv("HEVCE_CLUSTER")) { const int mx = atoi(e); if (mx >= 0 && mx < j->cluster) j->cluster = mx < 1 ? 1 : mx; }
+    }
+    j->cluster_now = j->cluster;
+    if (j->cluster > 1) {
+        if (hipHostMalloc((void **)&j->h_cluster_init, sizeof(HevceCluster), hipHostMallocDefault) != hipSuccess) { fail("hevce_job_create: pinned allocation failed"); hevce_job_destroy(j); return nullptr; }
+        memset(j->h_cluster_init, 0, sizeof(HevceCluster));      /* sequence words start at 0 */
     }
     if (getenv("HEVCE_DUMP")) {
         for (int i = 0; i < n; i++) j->dump_ints += size_t(j->im[i].nctu) * 21 * HEVCE_TRIALS * 16;
@@ -215,6 +252,8 @@ void hevce_job_destroy(hevce_job *j) {
     if (!j) return;
     (void)hipSetDevice(j->device);
     if (j->launched) (void)hipStreamSynchronize(j->stream);
+    if (j->cu_claimed) { cu_release(j->device, j->cu_claimed); j->cu_claimed = 0; }
+    if (j->h_cluster_init) (void)hipHostFree(j->h_cluster_init);
     if (j->d_slab) (void)hipFree(j->d_slab);
     if (j->d_desc) (void)hipFree(j->d_desc);
     if (j->h_slab) (void)hipHostFree(j->h_slab);
@@ -282,7 +321,7 @@ int hevce_job_set_flags(hevce_job *j, int flags) {
 int hevce_job_cluster(hevce_job *j, int *fallbacks) {
     if (!j) return fail("hevce_job_cluster: null job");
     if (fallbacks) *fallbacks = j->cluster_fallbacks;
-    return (j->cluster > 1 && !(j->flags & 2)) ? j->cluster : 1;
+    return j->cluster_now;                                       /* of the last launch (before any: what the device has room for) */
 }
 int hevce_job_stats(hevce_job *j, int i, int *out2) {
     if (!j || i < 0 || i >= j->n || !out2) return fail("hevce_job_stats: bad arguments");
@@ -294,6 +333,15 @@ int hevce_job_stats(hevce_job *j, int i, int *out2) {
 int hevce_job_launch(hevce_job *j) {
     if (!j) return fail("hevce_job_launch: null job");
     HIPCHK(hipSetDevice(j->device));
+    if (j->launched) return fail("hevce_job_launch: the previous launch has not been finished");
+    /* the cluster size of this launch: what fits beside this process's other launches in flight (their units come back at their finish) */
+    {
+        if (j->cu_claimed) { cu_release(j->device, j->cu_claimed); j->cu_claimed = 0; }
+        const int want = (j->cluster > 1 && !(j->flags & 2) && !j->single_once) ? j->cluster : 1;
+        j->single_once = false;
+        const int now = cu_claim(j->device, want > 1 ? (j->n + 7) & ~7 : j->n, want, j->cus, &j->cu_claimed);
+        if (now != j->cluster_now) { j->cluster_now = now; j->desc_dirty = true; }
+    }
     if (j->desc_dirty) {
         size_t dump_off = 0;
         for (int i = 0; i < j->n; i++) {
@@ -313,19 +361,19 @@ int hevce_job_launch(hevce_job *j) {
             d.payload = j->device_emit ? j->d_slab + m.off_payload : nullptr;
             d.stats = (int32_t *)(j->d_slab + m.off_stats);
             d.wr_tok = j->d_slab + m.off_wrtok;
-            d.cluster = (j->cluster > 1 && !(j->flags & 2)) ? (HevceCluster *)(j->d_slab + m.off_cluster) : nullptr;
+            d.cluster = j->cluster_now > 1 ? (HevceCluster *)(j->d_slab + m.off_cluster) : nullptr;
             d.flags = j->flags; d.pad_ = 0;
             d.payload_len = j->device_emit ? (int32_t *)(j->d_slab + m.off_plen) : nullptr;
         }
         HIPCHK(hipMemcpyAsync(j->d_desc, j->h_desc.data(), sizeof(HevceImageDesc) * j->n, hipMemcpyHostToDevice, j->stream));
         j->desc_dirty = false;
     }
-    const int cluster = (j->cluster > 1 && !(j->flags & 2)) ? j->cluster : 1;
+    const int cluster = j->cluster_now;
     if (cluster > 1) {
-        HevceCluster init;
-        memset(&init, 0, sizeof init);                           /* sequence words start at 0 */
-        init.size = cluster;
-        for (int i = 0; i < j->n; i++) HIPCHK(hipMemcpyAsync(j->d_slab + j->im[i].off_cluster, &init, sizeof init, hipMemcpyHostToDevice, j->stream));
+        /* (the pinned block belongs to the job and is only written here, behind the previous launch's finish: the copies below may still
+           be reading it when this call returns) */
+        j->h_cluster_init->size = cluster;
+        for (int i = 0; i < j->n; i++) HIPCHK(hipMemcpyAsync(j->d_slab + j->im[i].off_cluster, j->h_cluster_init, sizeof(HevceCluster), hipMemcpyHostToDevice, j->stream));
     }
     HIPCHK(hipEventRecord(j->ev0, j->stream));
     if (hevce_launch_analyse(j->d_desc, j->n, cluster, j->stream) != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -351,6 +399,7 @@ int hevce_job_finish(hevce_job *j) {
     HIPCHK(hipSetDevice(j->device));
     HIPCHK(hipEventSynchronize(j->ev2));
     j->launched = false;
+    if (j->cu_claimed) { cu_release(j->device, j->cu_claimed); j->cu_claimed = 0; }
     HIPCHK(hipEventElapsedTime(&j->kernel_ms, j->ev0, j->ev1));
     HIPCHK(hipEventElapsedTime(&j->d2h_ms, j->ev1, j->ev2));
     const auto t0 = std::chrono::steady_clock::now();
@@ -362,11 +411,11 @@ int hevce_job_finish(hevce_job *j) {
         for (int i = 0; i < j->n; i++) {
             Image &m = j->im[i];
             const int plen = *(const int32_t *)(j->h_slab + m.hoff_plen);
-            if (plen == -1 && j->cluster > 1 && !(j->flags & 2)) {
-                /* a hand-off between a picture's two workgroups timed out (they were not resident side by side): once more, one
-                   workgroup per picture */
-                fprintf(stderr, "hevce_mi355x: cluster hand-off timed out (image %d); encoding again without clusters\n", i);
-                j->cluster = 1; j->desc_dirty = true; j->cluster_fallbacks++;
+            if (plen == -1 && j->cluster_now > 1) {
+                /* the picture's workgroups were not resident side by side (the kernel's alive check, milliseconds) or a hand-off
+                   between them timed out: once more, one workgroup per picture */
+                fprintf(stderr, "hevce_mi355x: a cluster was not placed or a hand-off timed out (image %d); encoding again without clusters\n", i);
+                j->single_once = true; j->cluster_fallbacks++;   /* this launch only: the device may have room again for the next */
                 if (hevce_job_launch(j) != 0) return -1;
                 return hevce_job_finish(j);
             }
@@ -511,6 +560,13 @@ int hevce_job_download_rcon(hevce_job *j, int i, unsigned char *dst) {
 }
 
 void *hevce_job_device_rcon(hevce_job *j, int i) { return (j && i >= 0 && i < j->n) ? j->d_slab + j->im[i].off_rcon : nullptr; }
+const void *hevce_job_device_payload(hevce_job *j, int i, int *length) {
+    if (!j || i < 0 || i >= j->n || !j->device_emit || j->launched || !j->im[i].stream_ptr) return nullptr;
+    const int plen = *(const int32_t *)(j->h_slab + j->im[i].hoff_plen);
+    if (plen <= 0) return nullptr;
+    if (length) *length = plen;
+    return j->d_slab + j->im[i].off_payload;
+}
 void *hevce_job_device_records(hevce_job *j, int i) { return (j && i >= 0 && i < j->n) ? j->d_slab + j->im[i].off_rec : nullptr; }
 
 int hevce_job_download_records(hevce_job *j, int i, unsigned char *records, int *ctu_state) {

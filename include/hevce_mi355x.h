@@ -52,9 +52,17 @@ typedef struct hevce_job hevce_job;
 /* allocate device + pinned host buffers for n images of the given sizes on HIP device `device` */
 hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs, const int *qpd6s);
 void       hevce_job_destroy(hevce_job *job);
-/* copy image i from host memory (stride = xszs[i]) into the job's HBM buffer */
+/* copy image i from host memory (stride = xszs[i]) into the job's HBM buffer.
+   LIFETIME OF `img`: the copy is enqueued on the job's stream (hipMemcpyAsync), ordered before the kernel of the next launch.
+     - pageable memory (malloc, numpy, ...): the HIP runtime has staged the bytes when the call returns -- the caller may reuse or
+       free `img` at once;
+     - PINNED memory (hipHostMalloc / hipHostRegister): the copy is a true asynchronous DMA -- `img` must stay valid and unchanged
+       until hevce_job_finish() / hevce_job_run() of the launch that reads it has returned (or the caller has synchronised the
+       job's stream itself).
+   A caller that cannot tell which kind it holds keeps the buffer until the launch has finished. */
 int  hevce_job_upload(hevce_job *job, int i, const unsigned char *img);
-/* the same from a window of a larger host picture: yszs[i] rows of xszs[i] samples at origin, row stride `stride` */
+/* the same from a window of a larger host picture: yszs[i] rows of xszs[i] samples at origin, row stride `stride`; the lifetime rule of
+   hevce_job_upload() applies to the whole window */
 int  hevce_job_upload_window(hevce_job *job, int i, const unsigned char *origin, long stride);
 /* use an image that already lives in HBM (e.g. a torch tensor's data_ptr); the job does not own it */
 int  hevce_job_set_device_image(hevce_job *job, int i, const void *d_img);
@@ -77,6 +85,11 @@ const unsigned char *hevce_job_stream(hevce_job *job, int i, int *length);
 int  hevce_job_padded_size(hevce_job *job, int i, int *ysz, int *xsz);
 int  hevce_job_download_rcon(hevce_job *job, int i, unsigned char *img_rcon);
 void *hevce_job_device_rcon(hevce_job *job, int i);
+/* image i's slice data where the kernel wrote it, in HBM (everything of the stream behind the VPS/SPS/PPS/slice header, which is a
+   function of qpd6 and the padded size alone: hevce_write_header), and its length in bytes; valid from hevce_job_finish() to the job's
+   next launch.  For consumers on the device -- e.g. a collective that gathers the streams of several GPUs without a host round trip
+   (hevc-image-encoder-lite_amd/distributed.py gather_job_streams).  NULL before the first finished launch or in the host-writer mode. */
+const void *hevce_job_device_payload(hevce_job *job, int i, int *length);
 void *hevce_job_device_records(hevce_job *job, int i);
 int  hevce_job_download_records(hevce_job *job, int i, unsigned char *records, int *ctu_state /* 8 ints per CTU, may be NULL */);
 /* timings of the last run, milliseconds: kernel (HIP events on the launch stream), D2H wait, stream assembly on the host */

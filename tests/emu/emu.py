@@ -44,7 +44,9 @@ def analyse(img, q, want_dump=False, flags=0, cluster=0):
     rc = lib().emu_analyse(img.ctypes.data_as(_u8p), h, w, q, rcon.ctypes.data_as(_u8p), rec.ctypes.data_as(_u8p),
                            st.ctypes.data_as(C.POINTER(C.c_int32)), dump.ctypes.data_as(C.POINTER(C.c_int32)) if want_dump else None,
                            payload.ctypes.data_as(_u8p), C.byref(plen), flags, stats.ctypes.data_as(C.POINTER(C.c_int32)), cluster)
-    assert rc == 0, "emulator deadlock" if rc == -1 else "cluster hand-off failed"
+    analyse.cluster_error = rc == -2                               # the kernel flagged the cluster (HevceCluster.error)
+    assert rc == 0 or (rc == -2 and (flags & 4)), "emulator deadlock" if rc == -1 else "cluster hand-off failed"
     analyse.stats = stats
     analyse.payload = bytes(payload[:max(plen.value, 0)])          # the slice data the device emitted itself
+    analyse.payload_len = plen.value
     return (rec, rcon, st, dump) if want_dump else (rec, rcon, st)

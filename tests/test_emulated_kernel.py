@@ -71,3 +71,14 @@ def test_emulated_cluster_of_workgroups(path, flags, nwg):
     assert np.array_equal(rcon, c["rcon"]) and np.array_equal(st, c["ctu_state"]) and np.array_equal(rec, c["records"])
     assert bytes(c["stream"]).endswith(emu.analyse.payload) and len(emu.analyse.payload) > 0
     assert emu.analyse.stats[1] == 0
+
+
+@pytest.mark.parametrize("nwg", [2, 4, 6])
+def test_emulated_cluster_is_given_up_when_a_workgroup_is_not_resident(nwg):
+    """flag bit 2: the workers leave before they report alive, as workgroups the device has not placed would; the chain workgroup's
+    alive wait (hv_cl_alive) flags the cluster before the first CTU and reports the picture as not encoded (payload length -1) --
+    the host then encodes it without clusters (tests/test_gpu_parity.py covers that side)."""
+    import emu
+    c = load_case(MODE_CASES[0])
+    emu.analyse(c["img"], c["q"], flags=4, cluster=nwg)
+    assert emu.analyse.cluster_error and emu.analyse.payload_len == -1 and emu.analyse.stats[1] > 0

@@ -289,6 +289,63 @@ def test_cluster_falls_back_when_its_workers_do_not_answer(hevce, orc):
             pytest.skip("the device is too small for clusters")
         job.set_flags(4)
         job.upload(0, img)
+        import time
+        t0 = time.time()
         job.run()
+        dt = time.time() - t0
         assert job.stream(0) == want and np.array_equal(job.rcon(0), wrc)
         assert job.cluster() == (1, 1)
+        # the chain workgroup's alive wait (hv_cl_alive; 1 ms under this flag, 20 ms otherwise) gives the cluster up before the first
+        # CTU: the whole detour -- failed launch, second launch without clusters -- is a matter of milliseconds, not of a hand-off timeout
+        assert dt < 1.0, dt
+        job.set_flags(0)                                         # the fall-back was for that launch only
+        job.run()
+        assert job.stream(0) == want and job.cluster()[0] >= 2 and job.cluster()[1] == 1
+
+
+def test_slice_data_on_the_device_and_gather_job_streams():
+    """hevce_job_device_payload + distributed.gather_job_streams on the device (tests/tools/gpu_gather_job.py, a process of its own
+    because torch has to bring up its HIP runtime before the library does)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "gpu_gather_job.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "gather from the device ok" in p.stdout, p.stdout + p.stderr
+
+
+def test_cluster_beside_a_batch_that_fills_the_device():
+    """a cluster's workgroups must be resident together.  tests/tools/gpu_saturate.py launches a batch that fills every compute unit
+    (and keeps refilling them) and, while it runs, a single picture: with the process-wide compute-unit accounting the picture takes
+    no cluster; with the accounting switched off (HEVCE_CU_BUDGET=0) it asks for one, and the kernel's alive check either sees the
+    whole cluster placed or gives it up within milliseconds.  Either way: right bytes, no multi-second stall."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for budget in ("1", "0"):
+        env = dict(os.environ, HEVCE_CU_BUDGET=budget)
+        p = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "gpu_saturate.py")], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        assert r["single_ok"] and r["batch_ok"], r
+        if budget == "1":
+            assert r["single_cluster"] == 1 and r["single_fallbacks"] == 0, r
+        assert r["single_extra_s"] < 2.0, r                      # beyond the batch's own duration
+
+
+@pytest.mark.parametrize("flags", [0, 16], ids=["light", "heavy"])
+def test_cluster_hand_offs_light_and_heavy(hevce, orc, flags):
+    """hand-offs between a cluster's workgroups: LIGHT when they share an XCD (no L2 maintenance), HEAVY -- agent-scope release / acquire
+    -- otherwise (hevce_device.h hv_publish_fence); flag bit 4 forces HEAVY everywhere.  Same bytes either way, no healed mismatches."""
+    import hevce_workload as wl
+    img = wl.gen_g2(160, 224, 16, seed=4242)
+    want, wrc = orc.encode(img, 2)
+    with hevce.Job([img.shape], 2) as job:
+        if job.cluster()[0] < 2:
+            pytest.skip("the device is too small for clusters")
+        job.set_flags(flags)
+        job.upload(0, img)
+        for _ in range(2):
+            job.run()
+            assert job.stream(0) == want and np.array_equal(job.rcon(0), wrc)
+            assert job.stats(0)[1] == 0 and job.cluster()[1] == 0

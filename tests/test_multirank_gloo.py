@@ -98,3 +98,43 @@ def _empty_worker(rank, world, port, q):
 
 def test_gather_with_an_empty_rank():
     assert _run(_empty_worker, base_port=33500) == [[], [b"abc", b""]]
+
+
+class _FinishedJob:
+    """what gather_job_streams reads of a finished hevc-image-encoder-lite_amd.Job, the oracle standing in for the device"""
+    def __init__(self, imgs, q):
+        import orc
+        self.n, self.qpd6 = len(imgs), [q] * len(imgs)
+        self._s = [orc.encode(im, q)[0] for im in imgs]
+        self._pad = [((im.shape[0] + 31) // 32 * 32, (im.shape[1] + 31) // 32 * 32) for im in imgs]
+
+    def padded_size(self, i):
+        return self._pad[i]
+
+    def stream(self, i):
+        return self._s[i]
+
+
+def _job_worker(rank, world, port, q):
+    """gather_job_streams: the size table + slice data travel, the receiver writes the parameter-set headers itself (the library's
+    hevce_write_header, which needs no device); rank 1 has two pictures of different sizes, rank 0 one"""
+    dist, D = _setup(rank, world, port)
+    import hevce_workload as wl
+    imgs = [wl.gen_g2(40 + 24 * k, 64 + 32 * rank, 16, seed=0x77 + 10 * rank + k) for k in range(1 + rank)]
+    job = _FinishedJob(imgs, 1 + rank)
+    got = D.gather_job_streams(job)
+    dist.barrier()
+    if rank == 0:
+        q.put([[hashlib.sha256(s).hexdigest() for s in part] for part in got])
+    else:
+        assert got is None
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gather_job_streams():
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hevce_workload as wl
+    import orc
+    got = _run(_job_worker, base_port=35500)
+    want = [[hashlib.sha256(orc.encode(wl.gen_g2(40 + 24 * k, 64 + 32 * r, 16, seed=0x77 + 10 * r + k), 1 + r)[0]).hexdigest() for k in range(1 + r)] for r in range(2)]
+    assert got == want

@@ -42,6 +42,7 @@ if kind == "phases":
     wk = tr[160:176].view(np.uint64).astype(float)
     if wk[5] > 0:
         print("  8x8 worker (cluster >= 4), k cycles per message: wait %.1f, accept %.1f, jobs %.1f, contexts+binarise %.1f, engines+answer %.1f" % tuple(wk[i] / wk[5] / 1e3 for i in range(5)))
+        print("    of the jobs stage: work items (to the last wavefront's end) %.1f, the candidates' engines %.1f   (HEVCE_FLAGS bit 5: the second 8x8 workgroup's numbers)" % (wk[6] / wk[5] / 1e3, wk[7] / wk[5] / 1e3))
         pw = tr[160:224].view(np.uint64).astype(float)[8:32].reshape(8, 3) / wk[5] / 1e3
         for wv in range(8):
             print("    wavefront %d: single-block trial items %.1f, TU-split slots (trials + tokens) %.1f, single-block token slots %.1f   (k cycles per CU; work items are handed out by a counter)" % (wv, pw[wv, 0], pw[wv, 1], pw[wv, 2]))
@@ -49,6 +50,9 @@ if kind == "phases":
         hs = p2[5:12] / nctu / 16 / 1e3
         print("  chain workgroup between two 8x8 jobs phases, k cycles per round: NxN report %.1f, wait for the answer %.1f, decision + commit %.1f, samples to HBM %.1f, "
               "enclosing CUs' decisions %.1f, entering the next CU (snapshot, level begin, CTU start / end work) %.1f, quad message or barrier %.1f" % (hs[1], hs[0], hs[3], hs[4], hs[2], hs[5], hs[6]))
+    if p2[15] > 0: print("  NxN pass (four modes of a 4x4 block, one helper wavefront), k cycles: block trials %.2f, binarisation %.2f" % (p2[13] / p2[15] / 1e3, p2[14] / p2[15] / 1e3))
+    wrp = tr[114:120].view(np.uint64).astype(float)
+    if wrp[2] > 0: print("  writer workgroup (clusters of five and more), k cycles per CTU: waiting for the chain %.1f, coding %.1f" % (wrp[0] / wrp[2] / 1e3, wrp[1] / wrp[2] / 1e3))
     print("  NxN chain:", "  ".join(f"{nm} {100.0*p2[i]/tot:5.1f}%" for i, nm in enumerate(("4x4 pipelines", "tokenise", "engine", "select", "tail"))))
 elif kind == "nxn":
     stages = nctu * 64
