@@ -86,8 +86,8 @@ typedef struct HevceNxn {      /* analysis workgroup -> 8x8 workgroup, once per 
     uint8_t ctx[104];          /* contexts after it */
     uint8_t rec[64];           /* its reconstruction, 8 x 8 */
 } HevceNxn;
-/* clusters of six: TWO 8x8 workgroups share the 8x8 CUs' candidates 0..69 (hevce_device.h hv_w8_mine); both read msg[2], the second
-   one answers in res[4] / res[5], and each takes the other's answer into its own decision of the CU.
+/* clusters of six / seven: TWO / THREE 8x8 workgroups share the 8x8 CUs' candidates 0..69 (hevce_device.h hv_w8_owner); all read msg[2],
+   workgroup g answers in res[2 + 2 g] / res[3 + 2 g], and each takes the others' answers into its own decision of the CU.
    mailboxes: msg / res 0: 16x16, 1: 32x32, msg 2: 8x8 (clusters of four: one message per 16x16 quad); the 8x8 answers alternate between
    res[2] and res[3] and the NxN reports between nxn[0] and nxn[1] (by the parity of the CU's number), so that neither side can
    overwrite what the other is still reading */
@@ -111,7 +111,7 @@ typedef struct HevceWrx {
    them before the first CTU, a few milliseconds at most (HV_CL_ALIVE_TIMEOUT): a cluster whose workgroups the device has not placed
    side by side -- other kernels hold the compute units -- is given up at once and the host encodes the picture without clusters.
    error: 1-4 a hand-off timed out, 5 a wavefront ran with lanes missing, 6 a workgroup of the cluster was not resident */
-typedef struct HevceCluster { HevceMsg msg[3]; HevceRes res[6]; HevceNxn nxn[2]; int32_t error; int32_t size; int32_t pad_[2]; int32_t alive[8]; HevceWrx wrx; } HevceCluster;
+typedef struct HevceCluster { HevceMsg msg[3]; HevceRes res[8]; HevceNxn nxn[2]; int32_t error; int32_t size; int32_t pad_[2]; int32_t alive[8]; HevceWrx wrx; } HevceCluster;
 
 /* one image of a batch, as the kernel sees it (all pointers are device pointers) */
 typedef struct HevceImageDesc {

@@ -32,6 +32,8 @@ static inline void hv_st_flag64(unsigned long long *p, unsigned long long v) { *
 static inline unsigned long long hv_ld_flag64(const unsigned long long *p) { return *p; }
 static inline int  hv_xcc_id() { return 0; }
 static inline void hv_spin_pause() { emu_yield(); }           /* lets the other workgroup's fibers run */
+static inline void hv_spin_backoff(int &) { emu_yield(); }
+static inline void hv_spin_long() { emu_yield(); }
 static inline void hv_spin_short() { emu_yield(); }
 static inline unsigned long long hv_realtime() { static unsigned long long t; return t += 1; }
 static inline unsigned hv_perm(unsigned a, unsigned b, unsigned sel) {
@@ -41,6 +43,7 @@ static inline unsigned hv_perm(unsigned a, unsigned b, unsigned sel) {
     return r;
 }
 static inline void hv_atomic_add(int *p, int v) { *p += v; }
+static inline void hv_atomic_or(int *p, int v) { *p |= v; }
 static inline int hv_shfl(int v, int src) {
     const int w = emu_cur >> 6, l = emu_cur & 63;
     emu_stage[w][l] = v;
@@ -103,6 +106,7 @@ static HD unsigned long long hv_ballot(int p) { return __ballot(p); }   /* one b
 static HD int  hv_clzll(unsigned long long v) { return __clzll((long long)v); }
 static HD unsigned hv_perm(unsigned a, unsigned b, unsigned sel) { return __builtin_amdgcn_perm(a, b, sel); }   /* v_perm_b32: result byte i = byte sel.byte[i] of {a:7..4, b:3..0} */
 static HD void hv_atomic_add(int *p, int v) { atomicAdd(p, v); }
+static HD void hv_atomic_or(int *p, int v) { atomicOr(p, v); }
 /* data-parallel primitives (DPP: the operand comes from another lane of the same row of 16 / quad of 4, no LDS involved):
    hv_row_get<s>(v): v of lane (l & ~15) | ((l + s) & 15)   [row_ror:16-s]      hv_quad_get<k>(v): v of lane (l & ~3) | k   [quad_perm] */
 template <int S_> static HD int hv_row_get(int v) { return (S_ & 15) ? __builtin_amdgcn_update_dpp(0, v, 0x120 + ((16 - S_) & 15), 0xf, 0xf, false) : v; }
@@ -144,6 +148,11 @@ static HD void hv_st_flag64(unsigned long long *p, unsigned long long v) { __hip
 static HD unsigned long long hv_ld_flag64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static HD int  hv_xcc_id() { int v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 15; }
 static HD void hv_spin_pause() { __builtin_amdgcn_s_sleep(2); }   /* between two polls of a word in HBM: 128 cycles (a hand-off is on the critical path) */
+/* ... of a wait that may be long (a worker workgroup waiting for its next message): after the first polls the pauses grow to 512 cycles.
+   Seven workgroups of a cluster polling one L2 channel 128 cycles apart slow the chain workgroup's own traffic there (measured: its
+   sections between two jobs phases 11.5 k -> 16.5 k cycles with the seventh workgroup) */
+static HD void hv_spin_long() { __builtin_amdgcn_s_sleep(8); }
+static HD void hv_spin_backoff(int &n) { if (n < 24) { n++; __builtin_amdgcn_s_sleep(2); } else __builtin_amdgcn_s_sleep(8); }
 static HD void hv_spin_short() { __builtin_amdgcn_s_sleep(1); }   /* between two polls of an LDS flag */
 static HD unsigned long long hv_realtime() { return __builtin_amdgcn_s_memrealtime(); }   /* 100 MHz */
 static HD unsigned hv_ldg_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   /* read at the L2: never a stale L1 line */
@@ -326,6 +335,7 @@ struct alignas(16) HvLds {
     int   c70_len, c70_byp;                                 /* tokens / bypass bins of candidate 70's stream so far */
     int   c70_rd, nxn_magn[35];                             /* cluster of four: blocks candidate 70's rider has consumed; FAST, per mode of the current 4x4 block: tokens | bypass bins << 8 */
     int   nxq_go, nxq_done;                                 /* cluster of four: 4x4 blocks whose reference samples are laid out; helper wavefronts done, in all */
+    int   nxq_tmask;                                        /* ... passes of the current 4x4 block whose block trials are done (hv_nxq_unit) */
     int   c70_done, c70_seg[4], c70_pat;                    /* FAST: stages whose winner's tokens are in the stream (5: header known too); per stage offset | tokens << 16 | cbf << 31; the CU header's four prev_intra_luma_pred_flags */
     u8    nxn_ctx[HEVCE_NCTXP][HV_TL];                      /* context columns of the NxN chain's 35 modes (fresh per 4x4 block) */
     /* control */
@@ -2145,21 +2155,57 @@ static HD void hv_nxn_pass(HvLds &S, const HvPx4 &K, const HV_LDSP u16 *lut4, in
     if (slot == 2 && lane == 0) { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); S.prof2[13] += t1_ - t0_; S.prof2[14] += t2_ - t1_; S.prof2[15] += 1; }   /* (one helper's first pass) */
 #endif
 }
+/* The nine passes of a 4x4 block on the chain wavefront and its helpers.  A pass is two UNITS -- the block trials (~1.2 k cycles) and the
+   binarisation (~1.8 k) of its four modes -- and a wavefront issues one instruction per ~4.5 cycles whatever it runs, so what counts is
+   the longest wavefront.  Four helpers (clusters of four: wavefronts 1..4): two passes each, 6 k.  Six helpers (clusters of five and
+   more, where the stream writer has left the workgroup: + wavefronts 6 and 7): one pass each, and the two passes left over are split
+   into their units -- two helpers do those block trials FIRST, two others the binarisations behind their own pass: 4.8 k.
+   A unit: slot | 0x20 = a whole pass, slot = its block trials (reported in S.nxq_tmask), slot | 0x10 = its binarisation (waits for them). */
+static constexpr unsigned char hv_nxq_sched[2][7][3] = {
+    { { 0x28, 0xff, 0xff }, { 0x20, 0x21, 0xff }, { 0x22, 0x23, 0xff }, { 0x24, 0x25, 0xff }, { 0x26, 0x27, 0xff }, { 0xff, 0xff, 0xff }, { 0xff, 0xff, 0xff } },
+    { { 0x28, 0xff, 0xff }, { 0x06, 0x20, 0xff }, { 0x07, 0x21, 0xff }, { 0x22, 0x16, 0xff }, { 0x23, 0x17, 0xff }, { 0x24, 0xff, 0xff }, { 0x25, 0xff, 0xff } } };
+static HD void hv_nxq_units(HvLds &S, const HvPx4 &K, const HV_LDSP u16 *lut4, int q, int ty, int tx, int six, int who, int lane) {   /* who: 0 = the chain wavefront, 1 + h = helper h */
+#if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
+    const unsigned long long u0_ = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int u = hv_nxq_sched[1][who][k], u4 = hv_nxq_sched[0][who][k];
+        const int unit = hv_uni(six) ? u : u4;
+        if (unit == 0xff) break;
+        const int slot = unit & 15, m = 4 * slot + (lane >> 4), ok = m < HEVCE_NMODES;
+        if (unit & 0x20) hv_nxn_pass(S, K, lut4, q, ty, tx, slot, lane);
+        else if (!(unit & 0x10)) {
+            hv_tu4_px(S, K, lut4, q, ty, tx, m, ok, lane);
+            HV_FENCE_RELEASE();
+            WAVE_SYNC();
+            if (lane == 0) hv_atomic_or(&S.nxq_tmask, 1 << slot);
+        } else {
+            while (!((hv_poll(&S.nxq_tmask) >> slot) & 1)) hv_spin_short();
+            HV_FENCE_ACQUIRE();
+            hv_tok4_px(S, m, ok, lane);
+            WAVE_SYNC();
+        }
+    }
+#if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
+    if (lane == 0) S.prof2[24 + hv_uni(who)] += __builtin_amdgcn_s_memtime() - u0_;   /* this wavefront's units of the block, start to end */
+#endif
+}
 
-/* a helper wavefront of the NxN chain (cluster of four): for each of the CU's four 4x4 blocks, when the chain has laid out the
-   reference samples, the block trials of its 16 modes */
+/* a helper wavefront of the NxN chain (cluster of four and more): for each of the CU's four 4x4 blocks, when the chain has laid out the
+   reference samples, its units of the block (hv_nxq_units) */
 #define HV_NXN_HELPERS 4
-static HDN void hv_nxn_helper(int q, HvCu cu, int h) {
+static HDN void hv_nxn_helper(int q, HvCu cu, int h, int six) {
     HvLds &S = HV_S;
-    q = hv_uni(q); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x); h = hv_uni(h);
+    q = hv_uni(q); cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x); h = hv_uni(h); six = hv_uni(six);
     const int lane = hv_tid() & 63;
     HvPx4 K;
     hv_px4_consts(S, K, lane);
     const HV_LDSP u16 *lut4 = hv_lut4_lds(S, 1);
     for (int s = 0; s < 4; s++) {
         while (hv_poll(&S.nxq_go) <= s) hv_spin_short();
-        /* modes 8 h .. 8 h + 7, four per pass (the chain wavefront takes 32..34) */
-        for (int slot = 2 * h; slot < 2 * h + 2; slot++) hv_nxn_pass(S, K, lut4, q, cu.y + (s >> 1) * 4, cu.x + (s & 1) * 4, slot, lane);
+        HV_FENCE_ACQUIRE();
+        hv_nxq_units(S, K, lut4, q, cu.y + (s >> 1) * 4, cu.x + (s & 1) * 4, six, 1 + h, lane);
         HV_FENCE_RELEASE();
         if (lane == 0) hv_atomic_inc(&S.nxq_done);
     }
@@ -2181,36 +2227,49 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
         int l, lb, a, ar;
         hv_sub_avail(s, cu.L, cu.LB, cu.A, cu.AR, l, lb, a, ar);
         const int oy = (s >> 1) * 4, ox = (s & 1) * 4;
-        /* reference samples of this 4x4 (shared by all modes): corner, left + left-below, above + above-right  [ref :1502] */
-        if (lane < 17) {
+        /* reference samples of this 4x4 (shared by all modes): corner, left + left-below, above + above-right  [ref :1502].  Lane 0 the
+           corner, 1..8 the left column downwards, 9..16 the row above: one position each, read from the CU's own samples so far (inside
+           the CU) or the picture's; what is not available repeats its neighbour or the corner  [ref :196-257 for a 4x4 block] */
+        {
             const HV_LDSP u8 *inner = (const HV_LDSP u8 *)&S.nxn_crec[0][0];
             const int ty = cu.y + oy, tx = cu.x + ox;
-            int corner;
-            if (l && a)  corner = hv_px(S, inner, 0, cu.y, cu.x, 8, ty - 1, tx - 1);
-            else if (l)  corner = hv_px(S, inner, 0, cu.y, cu.x, 8, ty, tx - 1);
-            else if (a)  corner = hv_px(S, inner, 0, cu.y, cu.x, 8, ty - 1, tx);
-            else         corner = 128;
-            int v = corner;
-            if (lane >= 1 && lane <= 8) {
-                const int i = lane - 1;
-                if (i < 4) v = l ? hv_px(S, inner, 0, cu.y, cu.x, 8, ty + i, tx - 1) : corner;
-                else v = lb ? hv_px(S, inner, 0, cu.y, cu.x, 8, ty + i, tx - 1) : (l ? hv_px(S, inner, 0, cu.y, cu.x, 8, ty + 3, tx - 1) : corner);
-            } else if (lane >= 9) {
-                const int i = lane - 9;
-                if (i < 4) v = a ? hv_px(S, inner, 0, cu.y, cu.x, 8, ty - 1, tx + i) : corner;
-                else v = ar ? hv_px(S, inner, 0, cu.y, cu.x, 8, ty - 1, tx + i) : (a ? hv_px(S, inner, 0, cu.y, cu.x, 8, ty - 1, tx + 3) : corner);
+            const int side = lane >= 9, i = side ? lane - 9 : lane - 1;          /* (lane 0: i = -1) */
+            const int on = side ? a : l, on2 = side ? ar : lb;                   /* this side's first four, its second four */
+            int yy, xx, have;
+            if (lane == 0) { yy = (l && a) ? ty - 1 : (l ? ty : ty - 1); xx = (l && a) ? tx - 1 : (l ? tx - 1 : tx); have = l || a; }
+            else {
+                const int k = (i < 4 || on2) ? i : 3;                             /* second four missing: the fourth one again */
+                yy = side ? ty - 1 : ty + k; xx = side ? tx + k : tx - 1; have = on;
             }
-            S.nxn_bord[lane] = (u8)v;
+            const int ry = yy - cu.y, rx = xx - cu.x, in = ry >= 0 && ry < 8 && rx >= 0 && rx < 8;
+            const int vi = inner[hv_min(hv_max(ry, 0), 7) * 8 + hv_min(hv_max(rx, 0), 7)], vo = S.rec[yy + 1][xx + HV_RX];
+            int v = have ? (in ? vi : vo) : 128;
+            const int corner = hv_readlane(v, 0);
+            v = have ? v : corner;
+            if (lane < 17) S.nxn_bord[lane] = (u8)v;
         }
         WAVE_SYNC();
+#if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
+#define HV_NXQ(i) do { if (lane == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.prof2[16 + (i)] += n_ - nq_; nq_ = n_; } } while (0)
+        unsigned long long nq_ = p2_;
+        HV_NXQ(0);
+#else
+#define HV_NXQ(i) do { } while (0)
+#endif
         if constexpr (FAST) {
             /* block trials and binarisation with one lane per sample, four modes per pass (hv_nxn_pass): nine passes -- all here, or
                eight on four helper wavefronts (hv_nxn_helper) and the last one here */
             if (hv_uni(helpers)) {
+                const int nh = hv_uni(helpers);                  /* 4 or 6 helper wavefronts */
+                if (lane == 0) hv_flag_clear(&S.nxq_tmask);      /* (the helpers are through with the block before: their done count) */
                 HV_FENCE_RELEASE();
+                WAVE_SYNC();
                 if (lane == 0) hv_flag_set(&S.nxq_go, s + 1);
-                hv_nxn_pass(S, K, lut4, q, cu.y + oy, cu.x + ox, 8, lane);
-                while (hv_poll(&S.nxq_done) < HV_NXN_HELPERS * (s + 1)) hv_spin_short();
+                hv_nxq_units(S, K, lut4, q, cu.y + oy, cu.x + ox, nh == 6, 0, lane);
+                HV_NXQ(1);
+                while (hv_poll(&S.nxq_done) < nh * (s + 1)) hv_spin_short();
+                HV_FENCE_ACQUIRE();
+                HV_NXQ(2);
             } else for (int slot = 0; slot < 9; slot++) hv_nxn_pass(S, K, lut4, q, cu.y + oy, cu.x + ox, slot, lane);
         } else if (lane < HEVCE_NMODES) {
             int last;
@@ -2462,7 +2521,7 @@ static HD void hv_level_begin(HvLds &S, const HvCu cu) {
     }
     if (tid < HV_TL) { L.tdead[tid] = 0; L.tpos[tid] = 0; L.tlen[tid] = 0; }
     if (n == 8) for (int k = tid; k < 8 * 8; k += HV_NTHREADS) (&S.nxn_crec[0][0])[k] = 0;
-    if (n == 8 && tid == 0) { S.nxn_busy = 1; S.l0_active = 71; S.c70_done = 0; S.nxq_go = 0; S.nxq_done = 0; S.c70_rd = 0; }
+    if (n == 8 && tid == 0) { S.nxn_busy = 1; S.l0_active = 71; S.c70_done = 0; S.nxq_go = 0; S.nxq_done = 0; S.nxq_tmask = 0; S.c70_rd = 0; }
 }
 
 /* chunks per slot of the candidates a wavefront is binarising: rows of HEVCE_TOKEN_SLOTS + 2 bytes, row 0 = candidate t0, in
@@ -2972,20 +3031,31 @@ static HDN void hv_wr_engine(const HevceImageDesc &im_, int cw, int budget) {
 /* clusters of six: two 8x8 workgroups.  Workgroup 0 takes the single-block candidates 0..34 and the TU-split candidates 67..69 (the ninth
    slot of four modes), workgroup 1 the TU-split candidates 35..66; the better of their two answers -- on equal cost the higher
    candidate, [ref :1440, 1476] -- is "the 8x8 workgroup's answer" */
-static HD int hv_n8(const HevceImageDesc &im) { return (im.cluster && im.cluster->size >= 6) ? 2 : 1; }
-static HD int hv_w8_owner(int t, int n8) { return (n8 == 2 && t >= 35 && t < 67) ? 1 : 0; }
+static HD int hv_n8(const HevceImageDesc &im) { return !im.cluster ? 1 : (im.cluster->size >= 7 ? 3 : (im.cluster->size >= 6 ? 2 : 1)); }
+/* clusters of seven: three 8x8 workgroups -- a third each of the single-block candidates (0..15, 16..31, 32..34: their block trials come in
+   items of eight modes, their tokens in items of four) and of the TU-split candidates (modes 0..11, 12..23, 24..34): per workgroup at
+   most five trial items side by side and then at most four token items, ~28 k cycles instead of ~45 k */
+static HD int hv_w8_owner(int t, int n8) {
+    if (n8 == 2) return (t >= 35 && t < 67) ? 1 : 0;
+    if (n8 == 3) return t < 35 ? (t < 16 ? 0 : (t < 32 ? 1 : 2)) : (t < 47 ? 0 : (t < 59 ? 1 : 2));
+    return 0;
+}
 static HD int hv_w8_better(int ca, int wa, int cb, int wb) { return cb < ca || (cb == ca && wb > wa); }   /* answer b beats answer a */
 static HD void hv_cl_peek8(HvLds &S, const HevceImageDesc &im, int lane) {
     if (lane) return;
     const int k = S.cl_ans8 + 1, n8 = hv_n8(im);                 /* the CU of this round (its decision counts it) */
-    const unsigned long long *tag0 = (const unsigned long long *)&im.cluster->res[2 + (k & 1)].tag, *tag1 = (const unsigned long long *)&im.cluster->res[4 + (k & 1)].tag;
+    while (hv_poll(&S.c70_done) < 3 && !hv_peek(&S.cl_fail)) hv_spin_long();   /* (not before the chain's last 4x4 block: the answer is of no use earlier, and the polls share an L2 channel with every hand-off) */
     for (;;) {
-        const unsigned long long t0 = hv_ld_flag64(tag0), t1 = n8 == 2 ? hv_ld_flag64(tag1) : t0;
-        if ((((unsigned)t0 >> 8) & 0xffffff) == (unsigned)(k & 0xffffff) && (((unsigned)t1 >> 8) & 0xffffff) == (unsigned)(k & 0xffffff)) {
+        int all = 1, bw = 0, bc = 0;
+        for (int g = 0; g < n8; g++) {                           /* every 8x8 workgroup's answer; the best of them, on equal cost the higher candidate */
+            const unsigned long long t = hv_ld_flag64((const unsigned long long *)&im.cluster->res[2 + 2 * g + (k & 1)].tag);
+            all &= (((unsigned)t >> 8) & 0xffffff) == (unsigned)(k & 0xffffff);
+            const int w = (int)((unsigned)t & 0xff), c = (int)(t >> 32);
+            if (g == 0 || hv_w8_better(bc, bw, c, w)) { bw = w; bc = c; }
+        }
+        if (all) {
             hv_acquire_fence(S.cl_light);
-            const int w0 = (int)((unsigned)t0 & 0xff), c0 = (int)(t0 >> 32), w1 = (int)((unsigned)t1 & 0xff), c1 = (int)(t1 >> 32);
-            const int b = n8 == 2 && hv_w8_better(c0, w0, c1, w1);
-            S.pf.w = b ? w1 : w0; S.pf.cost = b ? c1 : c0; S.pf.k = k;
+            S.pf.w = bw; S.pf.cost = bc; S.pf.k = k;
             return;
         }
         if (hv_poll(&S.c70_done) >= 5 || hv_peek(&S.cl_fail)) return;
@@ -2994,7 +3064,12 @@ static HD void hv_cl_peek8(HvLds &S, const HevceImageDesc &im, int lane) {
 }
 static HD void hv_cl_report_nxn(HvLds &S, const HevceImageDesc &im, int lane);
 static HDN void hv_c70_rider(const HevceImageDesc &im, HV_GLOBAL u16 *c70, int q);
-static HDN void hv_nxn_helper(int q, HvCu cu, int h);
+static HDN void hv_nxn_helper(int q, HvCu cu, int h, int six);
+/* six helper wavefronts for the NxN chain of this round?  The workgroup's wavefronts 6 and 7 are free when the stream writer is a workgroup
+   of its own (clusters of five and more) -- except wavefront 6 in a CTU's first round, when it checks the CTU before (hv_verify_nxn) */
+static HD int hv_nxq_six(const HvLds &S, const HevceImageDesc &im, int k16, int m) {
+    return im.cluster != nullptr && im.cluster->size >= 5 && !(hv_uni(k16) == 0 && hv_uni(m) == 0 && hv_uni(S.nxv_pend));
+}
 static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, const HvCu c16, const HvCu c32, int k16, int m, int ctu, int wr_on, int cl) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
     const int wv = hv_uni(wave);
@@ -3005,11 +3080,11 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         /* the NxN chain; it also writes the token stream, slot list and engine state of its outcome, candidate 70, and
            clears S.nxn_busy shortly before its end */
         HV_GLOBAL u16 *c70 = hv_c70_area(s0, fast);
-        if (fast) hv_job_nxn<true>(wave, lane, q, c8, c70, hv_uni(cl) == 2);
+        if (fast) hv_job_nxn<true>(wave, lane, q, c8, c70, hv_uni(cl) == 2 ? (hv_nxq_six(S, im, k16, m) ? 6 : 4) : 0);
         else hv_job_nxn<false>(wave, lane, q, c8, c70, 0);
         return;
     }
-    if (wv == (hv_uni(cl) == 2 ? 7 : 4)) {
+    if (wv == (hv_uni(cl) == 2 ? 7 : 4) && !(hv_uni(cl) == 2 && im.cluster->size >= 5)) {   /* (clusters of five and more: the writer is a workgroup of its own) */
         /* wavefront 4 shares its SIMD with wavefront 0, so no jobs: it writes the previous CTU's slice data instead (slice = this
            round's 8x8 position); the older wavefront 0 wins the SIMD's issue arbitration.  Cluster of four: wavefronts are to spare,
            the writer is wavefront 7 (measured: on wavefront 4 its slice, 91 k cycles, outlasted the NxN chain's 79 k and took issue
@@ -3035,9 +3110,11 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
     }
     if (hv_uni(cl) == 2) {                                       /* cluster of 4: this CU's block jobs and candidates 0..69 are another workgroup's */
         if (wv == 5) hv_c70_rider(im, hv_c70_area(s0, 1), q);      /* FAST analysis only (cl == 2); it also reports the candidate to the 8x8 workgroup */
-        if (wv >= 1 && wv <= 4) hv_nxn_helper(q, c8, wv - 1);      /* the NxN chain's block trials and binarisation, 8 modes each */
+        const int six = hv_nxq_six(S, im, k16, m);
+        if (wv >= 1 && wv <= 4) hv_nxn_helper(q, c8, wv - 1, six);   /* the NxN chain's block trials and binarisation (hv_nxq_units) */
         if (wv == 4) hv_cl_peek8(S, im, lane);                    /* then: the 8x8 workgroup's answer, noticed while the chain winds up */
         if (wv == 6 && k16 == 0 && m == 0 && hv_uni(S.nxv_pend)) hv_verify_nxn(lane, 1);   /* the previous CTU's NxN winners, off the critical path */
+        if (wv >= 6 && six) hv_nxn_helper(q, c8, wv - 2, six);    /* the stream writer is a workgroup of its own: two more helpers */
         return;
     }
     const int w1 = wv < 4 ? wv - 1 : wv - 2;                     /* work slot 0..5 */
@@ -3479,8 +3556,7 @@ static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu
     if (!pf) {
         if (tid == 0) {
             const unsigned long long to = (im.flags & 4) ? 100000ull : HV_CL_TIMEOUT;   /* test hook, see hv_cl_receive */
-            if (!hv_cl_wait(&im.cluster->res[2 + (k & 1)].seq, k, &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
-            if (n8 == 2 && !hv_cl_wait(&im.cluster->res[4 + (k & 1)].seq, k, &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
+            for (int g = 0; g < n8; g++) if (!hv_cl_wait(&im.cluster->res[2 + 2 * g + (k & 1)].seq, k, &S.cl_fail, S.cl_light, to)) im.cluster->error = 1;
         }
         BLOCK_SYNC();
     }
@@ -3488,9 +3564,13 @@ static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu
     int wa, ca;
     if (pf) { wa = hv_min(hv_uni(S.pf.w), 69); ca = hv_uni(S.pf.cost); }
     else {
-        const HevceRes *r0 = &im.cluster->res[2 + (k & 1)], *r1 = &im.cluster->res[4 + (k & 1)];
+        const HevceRes *r0 = &im.cluster->res[2 + (k & 1)];
         wa = hv_min(hv_max(hv_ldc_i32(&r0->winner), 0), 69); ca = hv_ldc_i32(&r0->cost);
-        if (n8 == 2) { const int wb = hv_min(hv_max(hv_ldc_i32(&r1->winner), 0), 69), cb = hv_ldc_i32(&r1->cost); if (hv_w8_better(ca, wa, cb, wb)) { wa = wb; ca = cb; } }
+        for (int g = 1; g < n8; g++) {
+            const HevceRes *r1 = &im.cluster->res[2 + 2 * g + (k & 1)];
+            const int wb = hv_min(hv_max(hv_ldc_i32(&r1->winner), 0), 69), cb = hv_ldc_i32(&r1->cost);
+            if (hv_w8_better(ca, wa, cb, wb)) { wa = wb; ca = cb; }
+        }
     }
     const int slot = 2 + 2 * hv_w8_owner(wa, n8) + (k & 1);
     const HevceRes *r = &im.cluster->res[slot];                  /* the answer of the workgroup that candidate came from */
@@ -3503,10 +3583,11 @@ static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu
         S.winner = w;
         if (win70) { S.com = L.tregs[70]; S.com.nbits -= L.tnlog[70]; }
         else { S.com = S.ent[0]; S.com.range = hv_ldc_i32(&r->range); S.com.nbits = hv_ldc_i32(&r->nbits); }
-        int ok = S.cl_ok | (hv_ldc_i32(&im.cluster->res[2 + (k & 1)].pad_[0]) == 1 ? 4 : 0);   /* all of the cluster on this XCD: light hand-offs (hv_cl_receive) */
-        if (n8 == 2) ok |= hv_ldc_i32(&im.cluster->res[4 + (k & 1)].pad_[0]) == 1 ? 8 : 0;
+        int ok = S.cl_ok;                                        /* all of the cluster on this XCD: light hand-offs (hv_cl_receive) */
+        for (int g = 0; g < n8; g++) ok |= hv_ldc_i32(&im.cluster->res[2 + 2 * g + (k & 1)].pad_[0]) == 1 ? 4 << g : 0;
         S.cl_ok = ok;
-        if ((ok & (n8 == 2 ? 15 : 7)) == (n8 == 2 ? 15 : 7) && !(im.flags & 16)) S.cl_light = 1;
+        const int need8 = 3 | (((1 << n8) - 1) << 2);
+        if ((ok & need8) == need8 && !(im.flags & 16)) S.cl_light = 1;
     }
     if (tid >= 64 && tid < 64 + HEVCE_NCTXP) S.com_ctx[tid - 64] = win70 ? L.tctx[tid - 64][70] : (u8)hv_ldc_u8(&r->ctx[tid - 64]);
     const int kindw = w < 35 ? 0 : (w < 70 ? 1 : 2);
@@ -3833,7 +3914,7 @@ static HD void hv_w8_split_slot(HvLds &S, const HevceImageDesc &im, HvW8 &W, con
 /* work item: the tokens of the single-block candidates 4 slot .. 4 slot + 3 (their block trials: hv_job_single<8>)  [ref :1434-1435] */
 static HD void hv_w8_single_slot(HvLds &S, HvW8 &W, int slot, HvGLev glev, int lane) {
     HvLds::Level &L = S.lv[0];
-    const int ii = lane & 15, m0 = 4 * slot + (lane >> 4), ok = m0 < HEVCE_NMODES, t = ok ? m0 : 0;
+    const int ii = lane & 15, m0 = 4 * slot + (lane >> 4), ok = m0 < HEVCE_NMODES, t = ok ? m0 : 4 * slot;   /* (lanes without a mode: the slot's first one again -- its block trial is this workgroup's) */
     const int kind = hv_scan_kind(8, t);
     HvGrp G;
     hv_tokcu(S, W, L, G, t, ok, t, 0, lane);
@@ -3856,7 +3937,11 @@ static HD void hv_w8_single_slot(HvLds &S, HvW8 &W, int slot, HvGLev glev, int l
 /* all 70 candidates of the 8x8 CU: results where hv_pw_stage's arg-min expects them (L.tcost / tsse / tregs / tnlog / tctx) */
 /* clusters of six: which work items / candidates are 8x8 workgroup g's (items 0..4: single-block trials, 5..13: TU-split slots, 14..22: the
    single-block candidates' tokens) */
-static HD int hv_w8_mine_item(int id, int g, int n8) { return n8 == 1 || (g == 0 ? (id < 5 || id >= 13) : (id >= 5 && id < 13)); }
+static HD int hv_w8_mine_item(int id, int g, int n8) {
+    if (n8 == 2) return g == 0 ? (id < 5 || id >= 13) : (id >= 5 && id < 13);
+    if (n8 == 3) return g == (id < 5 ? (id < 2 ? 0 : (id < 4 ? 1 : 2)) : (id < 14 ? (id - 5) / 3 : (id - 14 < 4 ? 0 : (id - 14 < 8 ? 1 : 2))));
+    return 1;
+}
 static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLev glev, HvGRec grec, int g8) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
     HvLds::Level &L = S.lv[0];
@@ -3955,7 +4040,7 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
     if (stage == 0) {
         if (tid < HV_TL) { const int mine = tid >= lo && tid < hi && (cu.n != 8 || hv_w8_owner(tid, hv_n8(im)) == g8); L.tdead[tid] = !mine; L.tpos[tid] = mine ? 0 : -1; L.tlen[tid] = 0; }   /* candidate 70 (NxN) is never this workgroup's */
         if (tid == 0) L.best_cost = HV_I32MAX;
-        if (cu.n == 8 && (!(im.flags & 8) || hv_n8(im) == 2)) hv_w8_cu(S, im, cu, glev, grec, g8);   /* one lane per sample (flag bit 3: the round-2 path below) */
+        if (cu.n == 8 && (!(im.flags & 8) || hv_n8(im) >= 2)) hv_w8_cu(S, im, cu, glev, grec, g8);   /* one lane per sample (flag bit 3: the round-2 path below) */
         else if (cu.n == 8) {
             /* 3 chains (16 modes each, candidates 35..69) + 5 single blocks (8 modes each, candidates 0..34): one job per wavefront,
                and everything that follows for the candidates of that job -- binarisation, engines -- in the same wavefront: nothing
@@ -4076,15 +4161,21 @@ static HD int hv_pw_advance8(HvLds &S, const HevceImageDesc &im, const HvCu cu, 
     HevceCluster *C = im.cluster;
     if (tid == 0) {
         if (!hv_cl_wait(&C->nxn[k & 1].seq, k, &S.cl_fail, S.cl_light)) C->error = 2;
-        if (n8 == 2 && !hv_cl_wait(&C->res[2 + 2 * (g8 ^ 1) + (k & 1)].seq, k, &S.cl_fail, S.cl_light)) C->error = 2;   /* clusters of six: the other 8x8 workgroup's answer */
+        for (int g = 0; g < n8; g++)                             /* clusters of six / seven: the other 8x8 workgroups' answers */
+            if (g != g8 && !hv_cl_wait(&C->res[2 + 2 * g + (k & 1)].seq, k, &S.cl_fail, S.cl_light)) C->error = 2;
     }
     BLOCK_SYNC();
     if (hv_uni(S.cl_fail)) return 0;
     const HevceNxn *r = &C->nxn[k & 1];
-    const HevceRes *po = &C->res[2 + 2 * (g8 ^ 1) + (k & 1)];
     const int wm = hv_min(hv_max(S.winner, 0), 69), cm = L.tcost[wm];
-    const int wo = n8 == 2 ? hv_min(hv_max(hv_ldc_i32(&po->winner), 0), 69) : 0, co = n8 == 2 ? hv_ldc_i32(&po->cost) : 0;
-    const int other = n8 == 2 && hv_w8_better(cm, wm, co, wo);   /* the partner's candidate is the better one */
+    int wo = wm, co = cm, go = g8;                               /* the best answer of all, whose it is */
+    for (int g = 0; g < n8; g++) if (g != g8) {
+        const HevceRes *pg = &C->res[2 + 2 * g + (k & 1)];
+        const int wg = hv_min(hv_max(hv_ldc_i32(&pg->winner), 0), 69), cg = hv_ldc_i32(&pg->cost);
+        if (hv_w8_better(co, wo, cg, wg)) { wo = wg; co = cg; go = g; }
+    }
+    const int other = go != g8;                                  /* a partner's candidate is the better one */
+    const HevceRes *po = &C->res[2 + 2 * go + (k & 1)];
     const int w = other ? wo : wm;
     const int win70 = hv_ldc_i32(&r->cost) <= (other ? co : cm);
     HvGRec grec = (HvGRec)(hv_worker8_scratch(im, k) + HV_TL * 1024 * 2);
@@ -4124,7 +4215,7 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
     if (serve & 4) { hv_w8_init(S, tid); BLOCK_SYNC(); }
     HevceCluster *C = im.cluster;
     if (im.flags & 4) return;                                    /* test hook: a worker that never answers (as if it had not become resident) */
-    if (tid == 0) hv_st_flag(&C->alive[(serve & 4) ? 3 + 2 * g8 : (serve == 2 ? 2 : 1)], 1);   /* this workgroup is resident (hv_cl_alive) */
+    if (tid == 0) hv_st_flag(&C->alive[(serve & 4) ? (g8 == 0 ? 3 : 4 + g8) : (serve == 2 ? 2 : 1)], 1);   /* this workgroup is resident (hv_cl_alive); 8x8 workgroups: roles 3, 5, 6 */
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     if (tid < 32) S.prof2[tid] = 0;
     unsigned long long wt_ = __builtin_amdgcn_s_memtime();
@@ -4135,14 +4226,14 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
     for (;;) {
         if (tid == 0) {
             const unsigned long long t0 = hv_realtime();
-            int pick = 0;
+            int pick = 0, spins = 0;
             for (;;) {
                 if ((serve & 4) && hv_ld_flag(&C->msg[2].seq) == S.cl_seq[2] + 1) { pick = 4; break; }   /* an 8x8 CU (or the exit message) */
                 if ((serve & 1) && hv_ld_flag(&C->msg[0].seq) == S.cl_seq[0] + 1) { pick = 1; break; }   /* a 16x16 CU (or the exit message): first */
                 if (stage32 >= 0) { pick = 2; break; }                                                   /* the 32x32 CU in progress */
                 if ((serve & 2) && hv_ld_flag(&C->msg[1].seq) == S.cl_seq[1] + 1) { pick = 3; break; }   /* a new 32x32 CU (or the exit message) */
                 if (hv_realtime() - t0 > HV_CL_TIMEOUT) { pick = -1; C->error = 2; break; }
-                hv_spin_pause();
+                hv_spin_backoff(spins);
             }
             if (pick == 1 || pick == 3 || pick == 4) hv_acquire_fence(S.cl_light);
             S.cl_pick = pick;
@@ -4466,7 +4557,7 @@ static HD void hv_writer_worker(HvLds &S, const HevceImageDesc &im) {
         HV_WRP(wp_busy);
         if (tid == 0) {
             const unsigned long long t0 = hv_realtime();
-            int pick;
+            int pick, spins = 0;
             for (;;) {
                 const unsigned long long g = hv_ld_flag64((const unsigned long long *)&X->go);
                 const int e = (int)(g >> 32), cnt = (int)(unsigned)g;
@@ -4474,7 +4565,7 @@ static HD void hv_writer_worker(HvLds &S, const HevceImageDesc &im) {
                 if (e != epoch) { pick = 2; break; }
                 if (cnt > c) { pick = 1; break; }
                 if (hv_realtime() - t0 > HV_CL_TIMEOUT) { pick = 0; im.cluster->error = 4; break; }
-                hv_spin_pause();
+                hv_spin_backoff(spins);
             }
             hv_acquire_fence(0);
             S.cl_pick = pick;

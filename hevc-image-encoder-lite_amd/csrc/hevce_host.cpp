@@ -226,7 +226,7 @@ hevce_job *hevce_job_create(int device, int n, const int *yszs, const int *xszs,
         /* sizes: 2 = one more workgroup for the 16x16 and 32x32 CUs, 3 = one each, 4 = + one for the 8x8 CUs' candidates 0..69 (and
            the chain workgroup's freed wavefronts help the NxN chain), 5 = + the stream writer on a workgroup of its own, 6 = + a second
            8x8 workgroup (the candidates 0..69 shared between the two).  The per-candidate dump (HEVCE_DUMP) knows clusters up to 5 */
-        const int top = getenv("HEVCE_DUMP") ? 5 : 6;
+        const int top = getenv("HEVCE_DUMP") ? 5 : 7;          /* 7 = + a third 8x8 workgroup */
         j->cluster = 1;
         if (j->device_emit) for (int c = top; c >= 2; c--) if (c * n8 <= cus) { j->cluster = c; break; }
         if (const char *e = getenv("HEVCE_CLUSTER")) { const int mx = atoi(e); if (mx >= 0 && mx < j->cluster) j->cluster = mx < 1 ? 1 : mx; }

@@ -17,6 +17,7 @@ hevce_analyse_kernel(const HevceImageDesc *__restrict__ images, int nimages, int
     else if (role == 4) hv_writer_worker(HV_S, im);              /* clusters of five: the stream writer */
     else if (role == 3) hv_parent_worker(HV_S, im, 4, 0);
     else if (role == 5) hv_parent_worker(HV_S, im, 4, 1);       /* clusters of six: the second 8x8 workgroup */
+    else if (role == 6) hv_parent_worker(HV_S, im, 4, 2);       /* clusters of seven: the third */
     else hv_parent_worker(HV_S, im, cluster == 2 ? 3 : role);
 }
 

@@ -1,15 +1,18 @@
 /* TEST INFRASTRUCTURE: runs hv_analyse_image() of the product's device header on the CPU fiber emulator. */
 #define HEVCE_EMU 1
 #include "emu_rt.h"
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include "../../hevc-image-encoder-lite_amd/csrc/hevce_device.h"
 #include <vector>
 
 int emu_cur = 0;
 HvLds *emu_lds_ptr = nullptr;
-int emu_stage[48][64];
+int emu_stage[56][64];
 
 namespace {
-enum { NT = HV_NTHREADS, NWG = 6, STACK = 256 * 1024 };
+enum { NT = HV_NTHREADS, NWG = 7, STACK = 256 * 1024 };
 enum State { RUN, WAIT_WAVE, WAIT_BLOCK, DONE };
 struct Fiber { void *sp; State st; char *stack; };
 Fiber fib[NWG * NT];
@@ -48,6 +51,7 @@ void fiber_entry() {
     if (role == 4) hv_writer_worker(*g_lds[role], *g_im);
     else if (role == 3) hv_parent_worker(*g_lds[role], *g_im, 4, 0);
     else if (role == 5) hv_parent_worker(*g_lds[role], *g_im, 4, 1);
+    else if (role == 6) hv_parent_worker(*g_lds[role], *g_im, 4, 2);
     else if (role) hv_parent_worker(*g_lds[role], *g_im, g_nwg == 2 ? 3 : role);
     else hv_analyse_image(*g_lds[0], *g_im);
     fib[emu_cur].st = DONE;
@@ -61,6 +65,13 @@ void emu_wave_sync(void) {
     fib[emu_cur].st = WAIT_WAVE;
     wave_wait[emu_cur >> 6]++;
     yield_to_sched();
+}
+static void emu_segv(int) {                                  /* HEVCE_EMU_BT=1: where a fiber crashed */
+    void *bt[48];
+    const int n = backtrace(bt, 48);
+    backtrace_symbols_fd(bt, n, 2);
+    fprintf(stderr, "emu: fault in fiber %d (workgroup %d, thread %d)\n", emu_cur, emu_cur / NT, emu_cur % NT);
+    _exit(139);
 }
 void emu_yield(void) { yield_to_sched(); }                  /* stays runnable */
 void emu_block_sync(void) {
@@ -103,6 +114,7 @@ int emu_analyse(const uint8_t *img, int src_h, int src_w, int q, uint8_t *rcon, 
         memset(g_lds[g], 0xAB, sizeof(HvLds));                /* LDS is not zero-initialised on the GPU either */
     }
     g_im = &im;
+    if (getenv("HEVCE_EMU_BT")) signal(SIGSEGV, emu_segv);
     memset(wave_wait, 0, sizeof wave_wait); memset(block_wait, 0, sizeof block_wait); ndone = 0;
     for (int i = 0; i < nfib; i++) {
         fib[i].stack = (char *)aligned_alloc(64, STACK);

@@ -19,7 +19,7 @@ extern long long emu_tok_stat[4];   /* FAST trial slots: tokens, chunks, slots (
 void emu_wave_sync(void);
 void emu_block_sync(void);
 extern int  emu_cur;                 /* running fiber = workgroup * 512 + thread id */
-extern int  emu_stage[48][64];       /* shuffle staging, per wave (up to six workgroups) */
+extern int  emu_stage[56][64];       /* shuffle staging, per wave (up to seven workgroups) */
 
 #define WAVE_SYNC()  emu_wave_sync()
 #define BLOCK_SYNC() emu_block_sync()

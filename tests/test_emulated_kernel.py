@@ -59,7 +59,7 @@ def test_emulated_kernel_reanalysis_paths(path, flags):
     assert (redo > 0) == (flags != 1)
 
 
-@pytest.mark.parametrize("nwg", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("nwg", [2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("flags", [0, 2 << 8, 3 << 16, (3 << 16) | (4 << 24)], ids=["fast", "nxn2", "wr3", "wr3-back5"])
 @pytest.mark.parametrize("path", MODE_CASES, ids=lambda p: os.path.basename(p)[6:-4])
 def test_emulated_cluster_of_workgroups(path, flags, nwg):
@@ -73,7 +73,7 @@ def test_emulated_cluster_of_workgroups(path, flags, nwg):
     assert emu.analyse.stats[1] == 0
 
 
-@pytest.mark.parametrize("nwg", [2, 4, 6])
+@pytest.mark.parametrize("nwg", [2, 4, 7])
 def test_emulated_cluster_is_given_up_when_a_workgroup_is_not_resident(nwg):
     """flag bit 2: the workers leave before they report alive, as workgroups the device has not placed would; the chain workgroup's
     alive wait (hv_cl_alive) flags the cluster before the first CTU and reports the picture as not encoded (payload length -1) --

@@ -52,6 +52,8 @@ if kind == "phases":
               "enclosing CUs' decisions %.1f, entering the next CU (snapshot, level begin, CTU start / end work) %.1f, quad message or barrier %.1f" % (hs[1], hs[0], hs[3], hs[4], hs[2], hs[5], hs[6]))
     if p2[15] > 0: print("  NxN pass (four modes of a 4x4 block, one helper wavefront), k cycles: block trials %.2f, binarisation %.2f" % (p2[13] / p2[15] / 1e3, p2[14] / p2[15] / 1e3))
     wrp = tr[114:120].view(np.uint64).astype(float)
+    if p2[16] > 0: print("  NxN stage, the chain wavefront (k cycles per 4x4 block): reference samples %.2f, its own pass %.2f, waiting for the helpers %.2f" % tuple(p2[16:19] / nctu / 64 / 1e3))
+    if p2[24] > 0: print("    units of a 4x4 block, start to end (k cycles): chain wavefront %.2f, helpers" % (p2[24] / nctu / 64 / 1e3), " ".join("%.2f" % (v / nctu / 64 / 1e3) for v in p2[25:31]))
     wr2 = tr[120:128].view(np.uint64).astype(float)
     if wrp[2] > 0 and wr2.sum() > 0: print("    of the coding: binarisation %.1f, tokens into LDS %.1f, resolving the contexts %.1f, the coder %.1f" % tuple(wr2 / wrp[2] / 1e3))
     if wrp[2] > 0: print("  writer workgroup (clusters of five and more), k cycles per CTU: waiting for the chain %.1f, coding %.1f" % (wrp[0] / wrp[2] / 1e3, wrp[1] / wrp[2] / 1e3))
