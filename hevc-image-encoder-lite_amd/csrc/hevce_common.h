@@ -51,7 +51,7 @@ typedef struct HevceCoderRegs {
     int32_t  pad;
 } HevceCoderRegs;
 
-/* Cluster mode (two workgroups per picture, hevce_device.h hv_parent_worker): mailboxes in HBM between the workgroup that walks
+/* Cluster mode (two workgroups per picture, hevce_dev_workers.h hv_parent_worker): mailboxes in HBM between the workgroup that walks
    the picture's chain of 8x8 decisions and the ones that evaluate candidates for it.  index = (CU level + 2) % 3: 16x16, 32x32, 8x8. */
 typedef struct HevceMsg {      /* analysis workgroup -> parent workgroup: "evaluate this CU from this entry state" */
     int32_t seq;               /* message number on this mailbox, written last (release); 0 = none yet */
@@ -86,7 +86,7 @@ typedef struct HevceNxn {      /* analysis workgroup -> 8x8 workgroup, once per 
     uint8_t ctx[104];          /* contexts after it */
     uint8_t rec[64];           /* its reconstruction, 8 x 8 */
 } HevceNxn;
-/* clusters of six / seven: TWO / THREE 8x8 workgroups share the 8x8 CUs' candidates 0..69 (hevce_device.h hv_w8_owner); all read msg[2],
+/* clusters of six / seven: TWO / THREE 8x8 workgroups share the 8x8 CUs' candidates 0..69 (hevce_dev_rounds.h hv_w8_owner); all read msg[2],
    workgroup g answers in res[2 + 2 g] / res[3 + 2 g], and each takes the others' answers into its own decision of the CU.
    mailboxes: msg / res 0: 16x16, 1: 32x32, msg 2: 8x8 (clusters of four: one message per 16x16 quad); the 8x8 answers alternate between
    res[2] and res[3] and the NxN reports between nxn[0] and nxn[1] (by the parity of the CU's number), so that neither side can
@@ -140,7 +140,7 @@ typedef struct HevceImageDesc {
 #define HEVCE_WRTOK_BYTES   (3 * 64 * HEVCE_WRTOK_SLOT_WORDS * 2)            /* CU header, block header, group slot per 4x4 position */
 #define HEVCE_TRIALS        72                               /* 35 + 35 + 1 (+1 pad) trial slots */
 #define HEVCE_TOKEN_SLOT_WORDS 128                           /* 16-bit words per bin-token slot, EXACT streams (context bins + bypass chunks) */
-#define HEVCE_FTOKEN_SLOT_WORDS 32                           /* FAST streams: context bins only, at most 31 per slot (hevce_device.h hv_tok_finish) */
+#define HEVCE_FTOKEN_SLOT_WORDS 32                           /* FAST streams: context bins only, at most 31 per slot (hevce_dev_nxn.h hv_tok_finish) */
 #define HEVCE_TOKEN_SLOTS      70                            /* slots per trial: CU header + block headers + 4x4 groups */
 #define HEVCE_SINK_WORDS       8192                          /* finished-byte records per trial between two replays (a 32x32 CU: < 6200 bytes in all) */
 /* one CU level's trial scratch: levels + samples | FAST token slots | EXACT token slots | EXACT byte sinks.  The FAST analysis touches

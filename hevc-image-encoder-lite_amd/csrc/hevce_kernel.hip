@@ -8,7 +8,7 @@ hevce_analyse_kernel(const HevceImageDesc *__restrict__ images, int nimages, int
     /* cluster mode: `cluster` (2 .. 4) workgroups per picture -- the first walks the picture's chain of decisions, the others
        evaluate candidates for it: the 16x16 / 32x32 CUs (one workgroup for both levels, or one each), with four also the 8x8 CUs' */
     /* the workgroups of a picture get block ids that are equal modulo 8: consecutive ids go round the 8 XCDs, so a cluster sits
-       on one XCD and shares its L2 (hand-offs without L2 maintenance; checked at run time, hevce_device.h hv_publish_fence) */
+       on one XCD and shares its L2 (hand-offs without L2 maintenance; checked at run time, hevce_dev_base.h hv_publish_fence) */
     const int b = blockIdx.x, npad = (nimages + 7) & ~7;
     const int pic = cluster > 1 ? b % npad : b, role = cluster > 1 ? b / npad : 0;
     if (pic >= nimages) return;

@@ -13,9 +13,10 @@ _lib = None
 
 def build():
     so = os.path.join(HERE, "libhevce_emu.so")
+    import glob
     deps = [os.path.join(HERE, "emu_main.cpp"), os.path.join(HERE, "emu_rt.h"),
             os.path.join(CSRC, "hevce_device.h"), os.path.join(CSRC, "hevce_common.h"), os.path.join(CSRC, "hevce_quant.h"),
-            os.path.join(CSRC, "hevce_tables.h")]
+            os.path.join(CSRC, "hevce_tables.h")] + sorted(glob.glob(os.path.join(CSRC, "hevce_dev_*.h")))
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + HERE,
                                "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", so, deps[0]])

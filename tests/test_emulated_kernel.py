@@ -47,7 +47,7 @@ MODE_CASES = [p for p in small_cases() if any(k in p for k in ("lcg_100x70_q2", 
                          ids=["exact", "nxn2", "wr3", "every-ctu-both", "nxn3-wr2"])
 @pytest.mark.parametrize("path", MODE_CASES, ids=lambda p: os.path.basename(p)[6:-4])
 def test_emulated_kernel_reanalysis_paths(path, flags):
-    """FAST analysis + EXACT re-analysis of poisoned CTUs (hevce_device.h, hv_analyse_image): the test hooks poison CTUs
+    """FAST analysis + EXACT re-analysis of poisoned CTUs (hevce_dev_picture.h, hv_analyse_image): the test hooks poison CTUs
     the way an NxN winner / the writer would; the output must stay the golden one and the two coders must never disagree."""
     import emu
     c = load_case(path)
@@ -63,7 +63,7 @@ def test_emulated_kernel_reanalysis_paths(path, flags):
 @pytest.mark.parametrize("flags", [0, 2 << 8, 3 << 16, (3 << 16) | (4 << 24)], ids=["fast", "nxn2", "wr3", "wr3-back5"])
 @pytest.mark.parametrize("path", MODE_CASES, ids=lambda p: os.path.basename(p)[6:-4])
 def test_emulated_cluster_of_workgroups(path, flags, nwg):
-    """cluster mode (hevce_device.h hv_parent_worker): the chain workgroup and the parent workgroup(s) of one picture as 2 / 3 / 4 x 512
+    """cluster mode (hevce_dev_workers.h hv_parent_worker): the chain workgroup and the parent workgroup(s) of one picture as 2 / 3 / 4 x 512
     fibers exchanging messages through the HevceCluster mailboxes; also with re-analysed CTUs, which the chain workgroup does alone."""
     import emu
     c = load_case(path)

@@ -1,7 +1,7 @@
 """CPU: the product's FAST decision rule against the oracle proper.
 
 The HIP kernel decides with bit counts that leave out the emulation-prevention bytes of the trial encodes and re-analyses, with
-exact counts, the CTUs its stream writer / NxN verification flag (hevce_device.h, hv_fengine_chunk).
+exact counts, the CTUs its stream writer / NxN verification flag (hevce_dev_syntax.h, hv_fengine_chunk).
 oracle/hevce_oracle.c restates that rule (orc_analyse_fast_rule); here it must reproduce the oracle's records, reconstruction
 and per-CTU coder registers on pictures where such bytes are frequent: constant, faint noise, soft blobs, shallow ramps, one edge.
 tests/tools/fast_rule_sweep.py is the same check at 2 x 10^5 CTUs (profiles/r03_fast_rule_sweep.json)."""

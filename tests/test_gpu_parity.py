@@ -336,7 +336,7 @@ def test_cluster_beside_a_batch_that_fills_the_device():
 @pytest.mark.parametrize("flags", [0, 16], ids=["light", "heavy"])
 def test_cluster_hand_offs_light_and_heavy(hevce, orc, flags):
     """hand-offs between a cluster's workgroups: LIGHT when they share an XCD (no L2 maintenance), HEAVY -- agent-scope release / acquire
-    -- otherwise (hevce_device.h hv_publish_fence); flag bit 4 forces HEAVY everywhere.  Same bytes either way, no healed mismatches."""
+    -- otherwise (hevce_dev_base.h hv_publish_fence); flag bit 4 forces HEAVY everywhere.  Same bytes either way, no healed mismatches."""
     import hevce_workload as wl
     img = wl.gen_g2(160, 224, 16, seed=4242)
     want, wrc = orc.encode(img, 2)
