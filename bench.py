@@ -159,6 +159,7 @@ def main():
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         elapsed = float(e.item())
     redo, bad = job.stats(0)
+    wg_per_picture, repeated = job.cluster()                  # of the last launch: workgroups per picture, launches repeated without clusters
     job.close()
 
     pixels_per_step = H * W * world
@@ -264,7 +265,8 @@ def main():
             "config": {"workload": f"one {args.width}x{args.height} G2-16 grayscale picture per GPU (seed 0x1234ABCD+rank), "
                                    f"qpd6={args.qpd6}, padded {W}x{H} = {nctu} CTUs, input resident in HBM; "
                                    "kernel (analysis + slice data) + D2H + header" + ("; RCCL gather of streams to rank 0" if world > 1 else ""),
-                       "images_per_gpu": 1, "parallelism": f"image-per-gpu x{world}"},
+                       "images_per_gpu": 1, "parallelism": f"image-per-gpu x{world}",
+                       "workgroups_per_picture": wg_per_picture, "launches_repeated_without_clusters": repeated},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 6), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 9), "traffic": traffic, "traffic_scaled_from": traffic_src,
                          "kernel": "hevce_analyse_kernel", "kernel_ms_avg": round(k_avg, 3),

@@ -107,7 +107,8 @@ typedef struct HevceWrx {
     int32_t  xflag[8];         /* chain : CTU c was analysed EXACT (its emulation-prevention bytes are part of its bit counts) */
     uint8_t  snap[8][192];     /* chain : what CTU c starts from (HvLds::Snap) */
 } HevceWrx;
-/* alive[r]: workgroup r of the cluster has started (it is RESIDENT: its hand-offs will be answered).  The chain workgroup waits for all of
+/* alive[r]: workgroup r of the cluster has started (it is RESIDENT: its hand-offs will be answered); the word is 0x100 | its XCC id, so the
+   chain workgroup also learns whether the whole cluster shares its XCD (light hand-offs, hevce_dev_base.h hv_publish_fence).  The chain workgroup waits for all of
    them before the first CTU, a few milliseconds at most (HV_CL_ALIVE_TIMEOUT): a cluster whose workgroups the device has not placed
    side by side -- other kernels hold the compute units -- is given up at once and the host encodes the picture without clusters.
    error: 1-4 a hand-off timed out, 5 a wavefront ran with lanes missing, 6 a workgroup of the cluster was not resident */

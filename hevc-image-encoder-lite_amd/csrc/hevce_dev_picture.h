@@ -18,13 +18,15 @@ static HD void hv_snap_restore(HvLds &S, int ctu, int x0, int tid) {
 
 /* chain workgroup, before the first CTU: every other workgroup of the cluster has started (HevceCluster.alive).  One thread; returns 0
    and flags the cluster when one has not shown up in time */
-static HD int hv_cl_alive(const HevceImageDesc &im) {
+static HD int hv_cl_alive(const HevceImageDesc &im, int *same_xcd) {
     HevceCluster *C = im.cluster;
     const unsigned long long t0 = hv_realtime(), to = (im.flags & 4) ? 100000ull : HV_CL_ALIVE_TIMEOUT;   /* test hook: 1 ms */
+    const int me = hv_xcc_id();
+    hv_st_flag(&C->alive[0], 0x100 | me);                        /* (the writer workgroup reads it: light hand-offs with this one) */
     for (;;) {
-        int all = 1;
-        for (int r = 1; r < C->size; r++) all &= hv_ld_flag(&C->alive[r]) != 0;
-        if (all) return 1;
+        int all = 1, same = 1;
+        for (int r = 1; r < C->size; r++) { const int a = hv_ld_flag(&C->alive[r]); all &= a != 0; same &= (a & 0xff) == me; }
+        if (all) { *same_xcd = same; return 1; }
         if (hv_realtime() - t0 > to) { C->error = 6; return 0; }
         hv_spin_pause();
     }
@@ -66,7 +68,11 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     int epoch = 0;
     static_assert(sizeof(HvLds::Snap) == 192, "HevceWrx::snap holds an HvLds::Snap");
     if (im.cluster) {                                            /* all of the cluster is resident, or the picture is given back to the host at once */
-        if (tid == 0 && !hv_cl_alive(im)) S.cl_fail = 1;
+        if (tid == 0) {
+            int same = 0;
+            if (!hv_cl_alive(im, &same)) S.cl_fail = 1;
+            else if (same && !(im.flags & 16)) S.cl_light = 1;   /* the whole cluster on this XCD (the launch's layout, checked): light hand-offs from the start */
+        }
         BLOCK_SYNC();
     }
     while (!hv_uni(S.cl_fail)) {
@@ -329,7 +335,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
         }
         ctu++;
         if (wrx) {                                               /* the CTU's record and samples are final: the writer may have it */
-            hv_publish_fence(0);
+            hv_publish_fence(S.cl_light);                       /* (every thread's stores: record, samples, snapshot) */
             BLOCK_SYNC();
             if (tid == 0) hv_st_flag64((unsigned long long *)&X->go, ((unsigned long long)(unsigned)epoch << 32) | (unsigned)ctu);
         }

@@ -591,7 +591,7 @@ static HD void hv_parent_worker(HvLds &S, const HevceImageDesc &im, int serve, i
     if (serve & 4) { hv_w8_init(S, tid); BLOCK_SYNC(); }
     HevceCluster *C = im.cluster;
     if (im.flags & 4) return;                                    /* test hook: a worker that never answers (as if it had not become resident) */
-    if (tid == 0) hv_st_flag(&C->alive[(serve & 4) ? (g8 == 0 ? 3 : 4 + g8) : (serve == 2 ? 2 : 1)], 1);   /* this workgroup is resident (hv_cl_alive); 8x8 workgroups: roles 3, 5, 6 */
+    if (tid == 0) hv_st_flag(&C->alive[(serve & 4) ? (g8 == 0 ? 3 : 4 + g8) : (serve == 2 ? 2 : 1)], 0x100 | hv_xcc_id());   /* this workgroup is resident, and on which XCD (hv_cl_alive); 8x8 workgroups: roles 3, 5, 6 */
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     if (tid < 32) S.prof2[tid] = 0;
     unsigned long long wt_ = __builtin_amdgcn_s_memtime();

@@ -251,8 +251,11 @@ static HD void hv_writer_worker(HvLds &S, const HevceImageDesc &im) {
     const int nctu = (im.W >> 5) * (im.H >> 5);
     int c = 0, epoch = 0;
     if (im.flags & 4) return;                                    /* test hook: a worker that never answers */
-    if (tid == 0) hv_st_flag(&im.cluster->alive[4], 1);          /* this workgroup is resident (hv_cl_alive) */
-    if (tid == 0) { X->wregs[0] = S.wr; hv_publish_fence(0); hv_st_flag64((unsigned long long *)&X->wdone, 0ull); }
+    if (tid == 0) hv_st_flag(&im.cluster->alive[4], 0x100 | hv_xcc_id());   /* this workgroup is resident, and on which XCD (hv_cl_alive) */
+    if (tid == 0) { X->wregs[0] = S.wr; hv_publish_fence(0); hv_st_flag64((unsigned long long *)&X->wdone, 0ull); S.cl_light = 0; }
+    /* hand-offs with the chain workgroup: LIGHT (hv_publish_fence) once this workgroup knows that the chain sits on its XCD -- the chain
+       leaves its XCC id in alive[0] before anything else; until then, and with flag bit 4, agent-scope fences: each of those writes
+       the XCD's dirty L2 lines back (measured: 1.2 MB per CTU, the analysis' trial scratch, with two such fences per CTU) */
 #if defined(HEVCE_PROF) && !defined(HEVCE_EMU)
     if (tid < 32) S.prof2[tid] = 0;
     BLOCK_SYNC();
@@ -275,7 +278,8 @@ static HD void hv_writer_worker(HvLds &S, const HevceImageDesc &im) {
                 if (hv_realtime() - t0 > HV_CL_TIMEOUT) { pick = 0; im.cluster->error = 4; break; }
                 hv_spin_backoff(spins);
             }
-            hv_acquire_fence(0);
+            if (!S.cl_light && !(im.flags & 16)) { const int a0 = hv_ld_flag(&im.cluster->alive[0]); if (a0 && (a0 & 0xff) == hv_xcc_id()) S.cl_light = 1; }
+            hv_acquire_fence(S.cl_light);
             S.cl_pick = pick;
         }
         HV_WRP(wp_wait);
@@ -308,7 +312,7 @@ static HD void hv_writer_worker(HvLds &S, const HevceImageDesc &im) {
         if (tid == 0) {
             const int bad = (S.wr_epb > 0 && !hv_ldc_i32(&X->xflag[c & 7])) || S.winner;
             X->wregs[(c + 1) & 7] = S.wr;
-            hv_publish_fence(0);
+            hv_publish_fence(S.cl_light);
             if (bad) {
                 const unsigned long long wb = hv_ld_flag64((const unsigned long long *)&X->wbad);
                 if ((int)(wb >> 32) != epoch || (unsigned)wb == 0)
