@@ -297,8 +297,12 @@ static HDN void hv_nxn_helper(int q, HvCu cu, int h, int six) {
     }
 }
 
-/* NxN job (8x8 CU only): per 4x4 sub-block choose the mode with a fresh coder and fresh contexts  [ref :1499-1528] */
-template <bool FAST>
+/* NxN job (8x8 CU only): per 4x4 sub-block choose the mode with a fresh coder and fresh contexts  [ref :1499-1528].
+   PX: block trials and binarisation with one lane per sample / scan position on this wavefront and its helpers, resolved tokens (FAST,
+   clusters of four and more).  Without helpers (one workgroup per picture, clusters of two and three) the nine passes would all run
+   here, 27 k cycles per 4x4 block: there one lane per MODE does a block trial (~10 k), the binarisation (~8 k) and the engine
+   with a context look-up per bin (~7 k), as in round 2 -- batches of pictures run that path. */
+template <bool FAST, bool PX>
 static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c70, int helpers) {
     HvLds &S = HV_S;
     HvLds::Level &L = S.lv[0];
@@ -306,8 +310,8 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
     int total = 0;
     HV_PROF2_T0();
     HvPx4 K;
-    if constexpr (FAST) hv_px4_consts(S, K, lane);
-    const HV_LDSP u16 *lut4 = hv_lut4_lds(S, FAST && hv_uni(helpers));
+    if constexpr (PX) hv_px4_consts(S, K, lane);
+    const HV_LDSP u16 *lut4 = hv_lut4_lds(S, PX && hv_uni(helpers));
     if (lane == 0) { S.c70_len = 16; S.c70_byp = 0; }
     for (int s = 0; s < 4; s++) {
         int l, lb, a, ar;
@@ -342,9 +346,9 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
 #else
 #define HV_NXQ(i) do { } while (0)
 #endif
-        if constexpr (FAST) {
-            /* block trials and binarisation with one lane per sample, four modes per pass (hv_nxn_pass): nine passes -- all here, or
-               eight on four helper wavefronts (hv_nxn_helper) and the last one here */
+        if constexpr (PX) {
+            /* block trials and binarisation with one lane per sample, four modes per pass (hv_nxn_pass): nine passes, spread over this
+               wavefront and its helpers (hv_nxq_units) */
             if (hv_uni(helpers)) {
                 const int nh = hv_uni(helpers);                  /* 4 or 6 helper wavefronts */
                 if (lane == 0) hv_flag_clear(&S.nxq_tmask);      /* (the helpers are through with the block before: their done count) */
@@ -368,7 +372,7 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
         int cost = HV_I32MAX, idx = -1;
         if (lane < HEVCE_NMODES) {
             int bits, ntok, nbyp;
-            if constexpr (FAST) {
+            if constexpr (PX) {
                 /* the mode's resolved tokens are there (hv_tok4_px): the engine has no context to look up or to write back */
                 HV_PROF2(S, 1);
                 if (s == 3 && lane == 0) hv_flag_clear(&S.nxn_busy);     /* (see below) */
@@ -394,17 +398,25 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
                 hv_cg_load(S, g, (const HV_LDSP short *)S.nxn_lev[lane], 4, 2, ks, 0, S.nxn_last[lane], (u64)(S.nxn_sig[lane] ? 1 : 0), 1);
                 const int nb = hv_cg_emit(S, wb, g, 0);
 #pragma unroll
-                for (int i = 0; i < 8; i++) tk[HV_SLOT_TOK0 + na + nb + i] = (u16)HV_TOK_NOP;
+                for (int i = 0; i < 8; i++) tk[HV_SLOT_TOK0 + na + nb + i] = (u16)(FAST ? HV_TOK_NOPF : HV_TOK_NOP);
                 HV_PROF2(S, 1);
                 /* last block, only its engine to go: tell the candidates riding in the other wavefronts to wind up, so that they are
                    at the workgroup barrier when this wavefront gets there */
                 if (s == 3 && lane == 0) hv_flag_clear(&S.nxn_busy);
-                HvCod c;
-                hv_cod_fresh(c);
-                hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb, (HV_LDSP u16 *)S.nxn_sink[lane]);
-                hv_cod_replay(c, (const HV_LDSP HvChunk *)S.nxn_sink[lane]);
-                bits = hv_cod_bits(c);
-                ntok = na + nb; nbyp = 0;
+                if constexpr (FAST) {                            /* range-only engine with a context look-up per bin; the bypass bins were counted by the tokenisers */
+                    HvFCod c = { 510, 23 };
+                    hv_fengine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb);
+                    nbyp = wa.byp + wb.byp;
+                    bits = 23 - c.nbits + nbyp;
+                } else {
+                    HvCod c;
+                    hv_cod_fresh(c);
+                    hv_engine(S, c, cx, (const HV_LDSP HvChunk *)(tk + HV_SLOT_TOK0), na + nb, (HV_LDSP u16 *)S.nxn_sink[lane]);
+                    hv_cod_replay(c, (const HV_LDSP HvChunk *)S.nxn_sink[lane]);
+                    bits = hv_cod_bits(c);
+                    nbyp = 0;
+                }
+                ntok = na + nb;
             }
             S.nxn_ntok[lane] = ntok | (nbyp << 8) | (bits << 20);
             cost = hv_rdcost(q, S.nxn_sse[lane], bits);
@@ -440,7 +452,7 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
             const int pk = S.nxn_ntok[w];
             const int off = S.c70_len, cbf = S.nxn_sig[w], n = cbf ? (pk & 0xff) : 0;
             if (lane == 0) c70[off] = (u16)HV_CT(CX_YCBF, cbf);
-            if constexpr (FAST) {
+            if constexpr (PX) {
                 /* the plain halves of the winner's resolved tokens (<= 32): candidate 70 meets them in another context state.  With a rider
                    (cluster of four) they go to its wavefront's scratch tile, two blocks alternating: no round trip through the L2 */
                 const HV_LDSP unsigned *src = (const HV_LDSP unsigned *)S.nxn_tok[w] + HV_NXR_TOK;

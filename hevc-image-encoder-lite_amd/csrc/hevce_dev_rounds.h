@@ -64,8 +64,9 @@ static HD void hv_jobs_phase(HvLds &S, const HevceImageDesc &im, const HvCu c8, 
         /* the NxN chain; it also writes the token stream, slot list and engine state of its outcome, candidate 70, and
            clears S.nxn_busy shortly before its end */
         HV_GLOBAL u16 *c70 = hv_c70_area(s0, fast);
-        if (fast) hv_job_nxn<true>(wave, lane, q, c8, c70, hv_uni(cl) == 2 ? (hv_nxq_six(S, im, k16, m) ? 6 : 4) : 0);
-        else hv_job_nxn<false>(wave, lane, q, c8, c70, 0);
+        if (fast && hv_uni(cl) == 2) hv_job_nxn<true, true>(wave, lane, q, c8, c70, hv_nxq_six(S, im, k16, m) ? 6 : 4);
+        else if (fast) hv_job_nxn<true, false>(wave, lane, q, c8, c70, 0);   /* no helper wavefronts: one lane per mode */
+        else hv_job_nxn<false, false>(wave, lane, q, c8, c70, 0);
         return;
     }
     if (wv == (hv_uni(cl) == 2 ? 7 : 4) && !(hv_uni(cl) == 2 && im.cluster->size >= 5)) {   /* (clusters of five and more: the writer is a workgroup of its own) */
