@@ -29,6 +29,7 @@ static inline unsigned hv_perm(unsigned a, unsigned b, unsigned sel) {
 }
 static inline void hv_atomic_add(int *p, int v) { *p += v; }
 static inline void hv_atomic_or(int *p, int v) { *p |= v; }
+static inline void hv_lds_max(int *p, int v) { if (v > *p) *p = v; }
 static inline int hv_shfl(int v, int src) {
     const int w = emu_cur >> 6, l = emu_cur & 63;
     emu_stage[w][l] = v;
@@ -92,6 +93,7 @@ static HD int  hv_clzll(unsigned long long v) { return __clzll((long long)v); }
 static HD unsigned hv_perm(unsigned a, unsigned b, unsigned sel) { return __builtin_amdgcn_perm(a, b, sel); }   /* v_perm_b32: result byte i = byte sel.byte[i] of {a:7..4, b:3..0} */
 static HD void hv_atomic_add(int *p, int v) { atomicAdd(p, v); }
 static HD void hv_atomic_or(int *p, int v) { atomicOr(p, v); }
+static HD void hv_lds_max(__attribute__((address_space(3))) int *p, int v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 /* data-parallel primitives (DPP: the operand comes from another lane of the same row of 16 / quad of 4, no LDS involved):
    hv_row_get<s>(v): v of lane (l & ~15) | ((l + s) & 15)   [row_ror:16-s]      hv_quad_get<k>(v): v of lane (l & ~3) | k   [quad_perm] */
 template <int S_> static HD int hv_row_get(int v) { return (S_ & 15) ? __builtin_amdgcn_update_dpp(0, v, 0x120 + ((16 - S_) & 15), 0xf, 0xf, false) : v; }
@@ -314,6 +316,7 @@ struct alignas(16) HvLds {
             u16   nxv_info[64];                             /* last position | scan kind << 4 | has levels << 6 */
             short nxv_bits[64];                             /* the bit count the FAST engine gave it */
             u8    ftab[HV_FT_SIZE];                         /* context bytes a FRESH context set passes through (hv_set_mode): the resolved tokens of the NxN sub-search */
+            u8    t4c[128][32];                             /* context byte after k <= 4 bins ([byte][1 << k | bins, the first one in bit 0]): candidate 70's rider (it fills the union exactly) */
         };
     };
     int   nxn_ntok[35];                                     /* per mode of the current 4x4 block: tokens | bypass bins << 8 | bits << 20 */

@@ -16,6 +16,10 @@
 /* 70).  The engine (hv_rengine) then has no memory access on its dependency chain: perm -> sub -> select -> ffbh -> shift.       */
 /* --------------------------------------------------------------------------------------------- */
 #define HV_RTOK(cv, bin, plain) ((unsigned)(plain) | ((unsigned)(((cv) << 1) | (bin)) << 16))
+/* ... and, for whoever meets the same bins in ANOTHER state of the context (candidate 70's rider): how many bins of the same context the
+   block has before this one, and those bins, the first in bit 0 -- kp = k | bins << 3 (k <= 6: 9 bits), in bits 24..31 and bit 13 */
+#define HV_RTOK_KP(kp) ((((unsigned)(kp) & 0xffu) << 24) | ((((unsigned)(kp) >> 8) & 1u) << 13))
+#define HV_RTOK_GETKP(t) ((((t) >> 24) & 0xffu) | ((((t) >> 13) & 1u) << 8))
 #define HV_RTOK_NOP (((unsigned)(HV_PADCV << 1) << 16) | HV_TOK_NOPF)
 /* FAST rows of S.nxn_tok (288 bytes): resolved tokens as 32-bit words from word 4 (<= 8 + 15 + 9 and 8 no-ops), 16-byte aligned for
    the engine's chunk loads; from byte 224 the block's non-zero magnitudes in coding order, 16-bit */
@@ -149,7 +153,7 @@ static HD void hv_tok4_px(HvLds &S, int m, int ok, int lane) {
         const int b1 = (nzm >> e1) & 1, b2 = (nzm >> e2) & 1;
         const int k = ok1 + ok2, pre = ok1 ? (b1 | (ok2 ? b2 << 1 : 0)) : (ok2 ? b2 : 0);
         const int bin = (nzm >> ii) & 1;
-        row[(ok && ii < start) ? nlast + start - 1 - ii : HV_NXR_DUMMY] = HV_RTOK(S.ftab[HV_FT_SIG + cls * 8 + ((1 << k) | pre)], bin, HV_CT(CX_SIG + cls, bin));
+        row[(ok && ii < start) ? nlast + start - 1 - ii : HV_NXR_DUMMY] = HV_RTOK(S.ftab[HV_FT_SIG + cls * 8 + ((1 << k) | pre)], bin, HV_CT(CX_SIG + cls, bin)) | HV_RTOK_KP(k | (pre << 3));
     }
     /* ---- the non-zero magnitudes in coding order (highest position first): item t of the mode goes to lane t ---- */
     comp[(ok && v != 0) ? __builtin_popcount(nzm >> (ii + 1)) : 16 + ii] = (u16)av;      /* (16 + ii: the row's spare words behind) */
@@ -165,7 +169,8 @@ static HD void hv_tok4_px(HvLds &S, int m, int ok, int lane) {
         const int p0 = (int)(bigc >> ((fb + 1) & 15)) & ((1 << k0) - 1);
         const int at_ = c1 == 0 ? HV_FT_ONE0 + ((1 << k0) | p0) : (c1 == 3 ? HV_FT_ONE3 + (t - 2) : CX_ONE + c1);
         const int bin = at > 1;
-        row[(ok && t < n1) ? nlast + start + t : HV_NXR_DUMMY] = HV_RTOK(S.ftab[at_], bin, HV_CT(CX_ONE + c1, bin));
+        const int kp = c1 == 0 ? (k0 | (p0 << 3)) : (c1 == 3 ? t - 2 : 0);   /* context 3 has seen t - 2 zeros, context 0 the flags since the first level above 1 */
+        row[(ok && t < n1) ? nlast + start + t : HV_NXR_DUMMY] = HV_RTOK(S.ftab[at_], bin, HV_CT(CX_ONE + c1, bin)) | HV_RTOK_KP(kp);
         row[(ok && t == fb) ? nlast + start + n1 : HV_NXR_DUMMY] = HV_RTOK(S.ftab[CX_ABS], at > 2, HV_CT(CX_ABS, at > 2));
     }
     const int ntok = nlast + start + n1 + (fb < 8);
@@ -209,7 +214,7 @@ static HD void hv_rengine(const HvLds &S, HvFCod &c, ChunkPtr sp, int n) {
     {
         const HvChunk cur = sp[0];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { el[k] = S.ctab2[cur[k] >> 16][0]; en[k] = S.ctab2[cur[k] >> 16][1]; }
+        for (int k = 0; k < 4; k++) { el[k] = S.ctab2[(cur[k] >> 16) & 0xffu][0]; en[k] = S.ctab2[(cur[k] >> 16) & 0xffu][1]; }
     }
     HvChunk nxt = sp[1];
     for (int base = 0; base < n; base += 4) {
@@ -217,7 +222,7 @@ static HD void hv_rengine(const HvLds &S, HvFCod &c, ChunkPtr sp, int n) {
         nxt = sp[(base >> 2) + 2];
         unsigned nl[4], nn[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { nl[k] = S.ctab2[tk[k] >> 16][0]; nn[k] = S.ctab2[tk[k] >> 16][1]; }
+        for (int k = 0; k < 4; k++) { nl[k] = S.ctab2[(tk[k] >> 16) & 0xffu][0]; nn[k] = S.ctab2[(tk[k] >> 16) & 0xffu][1]; }
 #pragma unroll
         for (int k = 0; k < 4; k++) hv_rengine_step(c, el[k], en[k]);
 #pragma unroll
@@ -458,8 +463,8 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
                 const HV_LDSP unsigned *src = (const HV_LDSP unsigned *)S.nxn_tok[w] + HV_NXR_TOK;
                 if (hv_uni(helpers)) {
                     while (hv_poll(&S.c70_rd) < s - 1) hv_spin_short();      /* the rider is through with the block before the last one (same buffer) */
-                    HV_LDSP u16 *dst = (HV_LDSP u16 *)&S.ws[5] + (s & 1) * 64;
-                    if (lane < 48) dst[lane] = lane < n ? (u16)src[hv_min(lane, 39)] : (u16)HV_TOK_NOPF;   /* whole chunks of no-ops behind, and one more for the engine's prefetch */
+                    HV_LDSP unsigned *dst = (HV_LDSP unsigned *)&S.ws[5] + (s & 1) * 64;
+                    if (lane < 48) dst[lane] = lane < n ? src[hv_min(lane, 39)] : (unsigned)HV_TOK_NOPF;   /* (whole words: the rider needs each bin's predecessors, HV_RTOK_KP) */
                 } else if (lane < n) c70[off + 1 + lane] = (u16)src[lane];
             } else {
                 const HV_LDSP u16 *src = (const HV_LDSP u16 *)S.nxn_tok[w] + HV_SLOT_TOK0;

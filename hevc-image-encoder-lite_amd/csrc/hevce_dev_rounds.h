@@ -352,6 +352,12 @@ static HD void hv_set_mode(HvLds &S, int exact, int q, int tid) {
             for (int i = 0; i < k; i++) cv = hv_ctx_next(cv, (idx >> i) & 1);
             S.ftab[e] = (e == HV_CT_PAD) ? (u8)HV_PADCV : (u8)cv;
         }
+        for (int e = tid; e < 128 * 32; e += HV_NTHREADS) {
+            const int idx = e & 31, k = 31 - hv_clz((unsigned)hv_max(idx, 1));
+            int cv = e >> 5;
+            if (cv < 126) for (int i = 0; i < k; i++) cv = hv_ctx_next(cv, (idx >> i) & 1);
+            S.t4c[e >> 5][idx] = (u8)cv;
+        }
         if (tid < 48) {
             S.fx.sig4[tid >> 4][tid & 15] = hv_sig4info.v[tid >> 4][tid & 15];
             S.fx.scan4[tid >> 4][tid & 15] = hv_sig4info.scan[tid >> 4][tid & 15];
@@ -409,6 +415,7 @@ static HDN void hv_c70_rider(const HevceImageDesc &im, HV_GLOBAL u16 *c70, int q
     q = hv_uni(q);
     u8 *cx = &L.tctx[0][pl];                                     /* context columns 0..15 of the level: its candidates 0..69 live elsewhere */
     for (int r = lane >> 4; r < HEVCE_NCTXP; r += 4) L.tctx[r][pl] = S.ent_ctx[0][r];
+    for (int r = lane; r < HEVCE_NCTXP; r += 64) ((HV_LDSP int *)((HV_LDSP u8 *)&S.ws[hv_tid() >> 6] + 768))[r] = 0;
     WAVE_SYNC();
     HvFCod c = { S.ent[0].range, S.ent[0].nbits };
     if (act) {                                                                                              /* [ref :952-955, 985-1033] */
@@ -420,15 +427,45 @@ static HDN void hv_c70_rider(const HevceImageDesc &im, HV_GLOBAL u16 *c70, int q
     }
     for (int s = 0; s < 4; s++) {
         while (hv_poll(&S.c70_done) <= s) hv_spin_short();
+#if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
+        const unsigned long long rb_ = __builtin_amdgcn_s_memtime();
+#endif
         const int seg = hv_uni(S.c70_seg[s]), n = (seg >> 16) & 0x7fff, cbf = (seg >> 31) & 1;
-        const HV_LDSP u16 *stage = (const HV_LDSP u16 *)&S.ws[hv_tid() >> 6] + (s & 1) * 64;   /* the block's tokens, padded: put there by the chain (hv_job_nxn) */
-        if (act) {
-            *HV_CX(HV_CT_PAD) = HV_PADCV;
-            hv_fbin(S, c, HV_CX(CX_YCBF), cbf);                                                             /* [ref :1038-1043] */
-            hv_fengine(S, c, cx, (const HV_LDSP HvChunk *)stage, n);   /* the same bins in all sixteen lanes, each with its own range and contexts */
+        const HV_LDSP unsigned *stage = (const HV_LDSP unsigned *)&S.ws[hv_tid() >> 6] + (s & 1) * 64;   /* the block's tokens, padded: put there by the chain (hv_job_nxn) */
+        if (act) hv_fbin(S, c, HV_CX(CX_YCBF), cbf);                                                        /* [ref :1038-1043] */
+        /* The block's tokens are the same in all sixteen lanes and none is on the flags' context, so the context byte a bin meets is the
+           same in every lane: column 0's byte walked through the bin's predecessors of the same context in this block -- which the
+           chain's tokeniser has put into the token (HV_RTOK_KP: at most six, one or two look-ups in S.t4c).  One lane per token resolves,
+           the sixteen lanes then run an engine without context look-ups (hv_rengine, ~46 cycles per bin; with a look-up per bin
+           ~250: the last block's bins are on the round's critical path).  A context's byte after the block = after its last bin here:
+           the bin with the most predecessors (an LDS maximum per context). */
+        {
+            HV_LDSP u8 *tile = (HV_LDSP u8 *)&S.ws[hv_tid() >> 6];
+            HV_LDSP unsigned *rt = (HV_LDSP unsigned *)(tile + 512);                     /* 64 resolved tokens */
+            HV_LDSP int *cnt = (HV_LDSP int *)(tile + 768);                              /* per context: bins in this block (zero between blocks) */
+            HV_LDSP u8 *after = tile + 768 + 4 * HEVCE_NCTXP;                            /* [context][k]: the byte after its bin number k */
+            u8 *cx0 = &L.tctx[0][0];
+            const unsigned t = lane < n ? stage[lane] : (unsigned)HV_TOK_NOPF;
+            const int idx = (int)(((t & 0x1fffu) * 911u) >> 16), bin = (int)((t >> 14) & 1u), valid = lane < n && idx != HV_CT_PAD;
+            const int kp = (int)HV_RTOK_GETKP(t), k = kp & 7, pre = kp >> 3, k1 = hv_min(k, 4), k2 = k - k1;
+            const int c0 = valid ? cx0[idx * HV_TL] : 0;
+            const int s1 = S.t4c[c0][(1 << k1) | (pre & ((1 << k1) - 1))];
+            const int st = S.t4c[s1][(1 << k2) | (pre >> 4)];                            /* (k2 = 0: entry 1 is the byte itself) */
+            rt[lane] = valid ? HV_RTOK(st, bin, 0) : HV_RTOK_NOP;
+            if (valid) { after[idx * 8 + k] = S.t4c[st][2 | bin]; hv_lds_max(&cnt[idx], k + 1); }
+            WAVE_SYNC();
+            for (int r = lane; r < HEVCE_NCTXP; r += 64) {
+                const int m = cnt[r];
+                if (m) { cx0[r * HV_TL] = after[r * 8 + m - 1]; cnt[r] = 0; }
+            }
+            WAVE_SYNC();
+            if (act) hv_rengine(S, c, (const HV_LDSP HvChunk *)rt, n);
         }
         WAVE_SYNC();
         if (lane == 0) hv_flag_set(&S.c70_rd, s + 1);
+#if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
+        if (lane == 0) S.prof2[s == 3 ? 12 : 31] += __builtin_amdgcn_s_memtime() - rb_;   /* the rider's blocks: the last one / the others */
+#endif
     }
     while (hv_poll(&S.c70_done) < 5) hv_spin_short();
     const int pat = hv_uni(S.c70_pat) & 15;
@@ -438,7 +475,7 @@ static HDN void hv_c70_rider(const HevceImageDesc &im, HV_GLOBAL u16 *c70, int q
         L.tcost[70] = hv_rdcost(q, L.tsse[70], S.ent[0].nbits - c.nbits + byp);
         L.tdead[70] = 0; L.tpos[70] = -1;
     }
-    for (int r = lane; r < HEVCE_NCTXP; r += 64) L.tctx[r][70] = L.tctx[r][pat];
+    for (int r = lane; r < HEVCE_NCTXP; r += 64) L.tctx[r][70] = L.tctx[r][r == CX_YPM ? pat : 0];   /* the flags' context from the pattern's lane, everything else from column 0 */
     WAVE_SYNC();
     hv_cl_report_nxn(S, im, lane);
 }

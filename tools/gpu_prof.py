@@ -54,6 +54,7 @@ if kind == "phases":
     wrp = tr[114:120].view(np.uint64).astype(float)
     if p2[16] > 0: print("  NxN stage, the chain wavefront (k cycles per 4x4 block): reference samples %.2f, its own pass %.2f, waiting for the helpers %.2f" % tuple(p2[16:19] / nctu / 64 / 1e3))
     if p2[24] > 0: print("    units of a 4x4 block, start to end (k cycles): chain wavefront %.2f, helpers" % (p2[24] / nctu / 64 / 1e3), " ".join("%.2f" % (v / nctu / 64 / 1e3) for v in p2[25:31]))
+    if p2[12] > 0: print("  candidate 70's rider, k cycles per 4x4 block: the first three %.2f, the last one (the chain waits for it) %.2f" % (p2[31] / nctu / 48 / 1e3, p2[12] / nctu / 16 / 1e3))
     wr2 = tr[120:128].view(np.uint64).astype(float)
     if wrp[2] > 0 and wr2.sum() > 0: print("    of the coding: binarisation %.1f, tokens into LDS %.1f, resolving the contexts %.1f, the coder %.1f" % tuple(wr2 / wrp[2] / 1e3))
     if wrp[2] > 0: print("  writer workgroup (clusters of five and more), k cycles per CTU: waiting for the chain %.1f, coding %.1f" % (wrp[0] / wrp[2] / 1e3, wrp[1] / wrp[2] / 1e3))
