@@ -330,7 +330,8 @@ struct alignas(16) HvLds {
     int cl_seq[3];                                          /* cluster mode: messages sent (chain workgroup) / answered (parent workgroup) per mailbox; 8x8 worker: quads accepted */
     int cl_ans8;                                            /* 8x8 CUs reported (chain workgroup) / answered (8x8 workgroup) since the launch */
     struct Quad8 { int ctu; u8 y, x, L, LB, A, AR, ml0, ml2, ma0, ma2, pad_[2]; u8 pm[4][4]; };
-    struct Peek8 { int k, w, cost; };
+    struct Peek8 { int k, w, cost, dk; };                   /* dk: ... and its data have been fetched for CU dk (PeekD, hv_pfd) */
+    struct PeekD { int range, nbits; u8 ctx[HEVCE_NCTXP]; u8 rec[64]; short lev[64]; };   /* the winner's coder, contexts, samples, levels */
     union {
         Quad8 q8;                                           /* 8x8 workgroup: the quad it is walking */
         Peek8 pf;                                           /* chain workgroup: the answer to 8x8 CU pf.k has been seen (hv_cl_peek8): its winner and cost */

@@ -53,9 +53,15 @@ static HD void hv_cl_report_nxn(HvLds &S, const HevceImageDesc &im, int lane) {
     }
     for (int i = lane; i < HEVCE_NCTXP; i += 64) r->ctx[i] = L.tctx[i][70];
     r->rec[lane] = S.nxn_crec[lane >> 3][lane & 7];
+}
+/* ... and its sequence word, by the same wavefront BEHIND the barrier that ends the jobs phase: the wait for the stores above to have
+   left the compute unit (a round trip to the L2) is then beside the workgroup's decision instead of in front of the barrier; the 8x8
+   workgroups, who read the report, have the time */
+static HD void hv_cl_report_nxn_flag(HvLds &S, const HevceImageDesc &im, int lane) {
+    const int k = hv_uni(S.cl_ans8) + 1;
     hv_publish_fence(S.cl_light);
     WAVE_SYNC();
-    if (lane == 0) hv_st_flag(&r->seq, k);
+    if (lane == 0) hv_st_flag(&im.cluster->nxn[k & 1].seq, k);
 }
 /* chain workgroup, at the CU's decision: wait for the answer and make its candidate the only one alive of the level.  All threads. */
 static HD void hv_cl_receive(HvLds &S, const HevceImageDesc &im, const HvCu cu) {
@@ -94,6 +100,8 @@ static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu
     HvLds::Level &L = S.lv[0];
     const int k = hv_uni(S.cl_ans8) + 1, n8 = hv_n8(im);         /* this CU's number; counted below */
     const int pf = hv_uni(S.pf.k) == k;                          /* seen during the jobs phase (hv_cl_peek8; barriers since) */
+    const int pfd = pf && hv_uni(S.pf.dk) == k;                   /* ... and its data fetched */
+    const HvLds::PeekD &D = hv_pfd(S);
     HV_PROFC(S, -1);
     if (!pf) {
         if (tid == 0) {
@@ -124,25 +132,27 @@ static HD void hv_decide8_cluster(HvLds &S, const HevceImageDesc &im, const HvCu
     if (tid == 0) {
         S.winner = w;
         if (win70) { S.com = L.tregs[70]; S.com.nbits -= L.tnlog[70]; }
-        else { S.com = S.ent[0]; S.com.range = hv_ldc_i32(&r->range); S.com.nbits = hv_ldc_i32(&r->nbits); }
-        int ok = S.cl_ok;                                        /* all of the cluster on this XCD: light hand-offs (hv_cl_receive) */
-        for (int g = 0; g < n8; g++) ok |= hv_ldc_i32(&im.cluster->res[2 + 2 * g + (k & 1)].pad_[0]) == 1 ? 4 << g : 0;
-        S.cl_ok = ok;
-        const int need8 = 3 | (((1 << n8) - 1) << 2);
-        if ((ok & need8) == need8 && !(im.flags & 16)) S.cl_light = 1;
+        else { S.com = S.ent[0]; S.com.range = pfd ? D.range : hv_ldc_i32(&r->range); S.com.nbits = pfd ? D.nbits : hv_ldc_i32(&r->nbits); }
+        if (!S.cl_light && !(im.flags & 16)) {                   /* all of the cluster on this XCD: light hand-offs (hv_cl_receive; normally known since the alive check) */
+            int ok = S.cl_ok;
+            for (int g = 0; g < n8; g++) ok |= hv_ldc_i32(&im.cluster->res[2 + 2 * g + (k & 1)].pad_[0]) == 1 ? 4 << g : 0;
+            S.cl_ok = ok;
+            const int need8 = 3 | (((1 << n8) - 1) << 2);
+            if ((ok & need8) == need8) S.cl_light = 1;
+        }
     }
-    if (tid >= 64 && tid < 64 + HEVCE_NCTXP) S.com_ctx[tid - 64] = win70 ? L.tctx[tid - 64][70] : (u8)hv_ldc_u8(&r->ctx[tid - 64]);
+    if (tid >= 64 && tid < 64 + HEVCE_NCTXP) S.com_ctx[tid - 64] = win70 ? L.tctx[tid - 64][70] : (pfd ? D.ctx[tid - 64] : (u8)hv_ldc_u8(&r->ctx[tid - 64]));
     const int kindw = w < 35 ? 0 : (w < 70 ? 1 : 2);
     if (tid >= 256 && tid < 320) {
         const int p = tid - 256, yy = p >> 3, xx = p & 7;
-        S.rec[cu.y + yy + 1][cu.x + xx + HV_RX] = (kindw == 2) ? S.nxn_crec[yy][xx] : (u8)hv_ldc_u8((const u8 *)(grec + w * 1024 + p));
+        S.rec[cu.y + yy + 1][cu.x + xx + HV_RX] = (kindw == 2) ? S.nxn_crec[yy][xx] : (pfd ? D.rec[p] : (u8)hv_ldc_u8((const u8 *)(grec + w * 1024 + p)));
         int lv;
-        if (kindw == 0) lv = hv_ldc_i16((const short *)(glev + w * 1024 + hv_scan_idx(S, 3, hv_scan_kind(8, w), yy, xx)));
+        if (kindw == 0) { const int li = hv_scan_idx(S, 3, hv_scan_kind(8, w), yy, xx); lv = pfd ? D.lev[li] : hv_ldc_i16((const short *)(glev + w * 1024 + li)); }
         else {
             const int s4 = (yy >= 4) * 2 + (xx >= 4);
             const int md = kindw == 1 ? w - 35 : S.nxn_modes[s4];
             const int si = hv_scan_idx(S, 2, hv_scan_kind(4, md), yy & 3, xx & 3);
-            lv = kindw == 1 ? hv_ldc_i16((const short *)(glev + w * 1024 + s4 * 16 + si)) : S.nxn_bestlev[s4][si];
+            lv = kindw == 1 ? (pfd ? D.lev[s4 * 16 + si] : hv_ldc_i16((const short *)(glev + w * 1024 + s4 * 16 + si))) : S.nxn_bestlev[s4][si];
         }
         rec->lev[cu.y + yy][cu.x + xx] = (short)lv;
     }

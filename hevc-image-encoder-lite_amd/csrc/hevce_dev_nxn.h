@@ -210,24 +210,23 @@ static HD void hv_rengine_step(HvFCod &c, unsigned lps4, unsigned nx) {
 template <typename ChunkPtr>
 static HD void hv_rengine(const HvLds &S, HvFCod &c, ChunkPtr sp, int n) {
     if (n <= 0) return;
-    unsigned el[4], en[4];
-    {
-        const HvChunk cur = sp[0];
+    /* eight bins per turn of the loop, two register sets taking turns (a rotation of one set cost eight moves per four bins); the
+       streams end in at least eight no-op tokens, and their rows have room for the look-ahead behind those */
+    unsigned al[4], an[4], bl[4], bn[4];
+#define HV_RENG_LOAD(L_, N_, CH_) do { const HvChunk ch_ = (CH_); _Pragma("unroll") for (int k = 0; k < 4; k++) { L_[k] = S.ctab2[(ch_[k] >> 16) & 0xffu][0]; N_[k] = S.ctab2[(ch_[k] >> 16) & 0xffu][1]; } } while (0)
+    HV_RENG_LOAD(al, an, sp[0]);
+    HvChunk c1 = sp[1], c2 = sp[2];
+    for (int base = 0; base < n; base += 8) {
+        HV_RENG_LOAD(bl, bn, c1);
+        c1 = sp[(base >> 2) + 3];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { el[k] = S.ctab2[(cur[k] >> 16) & 0xffu][0]; en[k] = S.ctab2[(cur[k] >> 16) & 0xffu][1]; }
+        for (int k = 0; k < 4; k++) hv_rengine_step(c, al[k], an[k]);
+        HV_RENG_LOAD(al, an, c2);
+        c2 = sp[(base >> 2) + 4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) hv_rengine_step(c, bl[k], bn[k]);
     }
-    HvChunk nxt = sp[1];
-    for (int base = 0; base < n; base += 4) {
-        const HvChunk tk = nxt;
-        nxt = sp[(base >> 2) + 2];
-        unsigned nl[4], nn[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { nl[k] = S.ctab2[(tk[k] >> 16) & 0xffu][0]; nn[k] = S.ctab2[(tk[k] >> 16) & 0xffu][1]; }
-#pragma unroll
-        for (int k = 0; k < 4; k++) hv_rengine_step(c, el[k], en[k]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { el[k] = nl[k]; en[k] = nn[k]; }
-    }
+#undef HV_RENG_LOAD
 }
 /* one pass: the block trials and the binarisation of the four modes 4 * slot .. 4 * slot + 3 (whole wavefront) */
 static HD void hv_nxn_pass(HvLds &S, const HvPx4 &K, const HV_LDSP u16 *lut4, int q, int ty, int tx, int slot, int lane) {

@@ -54,7 +54,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
     const int force_exact = (im.flags & 1) || !im.payload;      /* without the writer nothing vouches for the FAST decisions */
     const int pk_nxn = (im.flags >> 8) & 0xff, pk_wr = (im.flags >> 16) & 0xff;
     hv_set_mode(S, force_exact, q, tid);
-    if (tid == 0) { S.poison = 0; S.nxv_pend = 0; S.poison_prev = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_ans8 = 0; S.pf.k = 0; S.cl_fail = 0; S.cl_light = 0; S.cl_ok = 0; }
+    if (tid == 0) { S.poison = 0; S.nxv_pend = 0; S.poison_prev = 0; S.wr_done = 0; S.cl_seq[0] = S.cl_seq[1] = S.cl_seq[2] = 0; S.cl_ans8 = 0; S.pf.k = 0; S.pf.dk = 0; S.cl_fail = 0; S.cl_light = 0; S.cl_ok = 0; }
     BLOCK_SYNC();
     hv_init_sigtab(S, tid);
     const int lut4_lds = im.cluster != nullptr && im.cluster->size >= 4;   /* cluster of four: the NxN chain's helpers look the 4x4 levels up in LDS */
@@ -183,6 +183,7 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
                     BLOCK_SYNC();                                /* the NxN job borrows the 8x8 level's context columns */
+                    if (cl8 && (tid >> 6) == 5) hv_cl_report_nxn_flag(S, im, tid & 63);   /* the rider's wavefront: its report's sequence word */
 #ifdef HEVCE_PROF_WAIT
                     if (tid == 0) S.prof2[16 + k * 4 + m] += __builtin_amdgcn_s_memtime() - w0_;
 #endif

@@ -25,26 +25,46 @@ static HD int hv_w8_owner(int t, int n8) {
     return 0;
 }
 static HD int hv_w8_better(int ca, int wa, int cb, int wb) { return cb < ca || (cb == ca && wb > wa); }   /* answer b beats answer a */
+/* (the prefetched winner lives in wavefront 1's scratch tile: in clusters of four and more that wavefront is an NxN helper, whose passes use
+   no tile; the LDS image has no room of its own left in the probe builds) */
+static HD HvLds::PeekD &hv_pfd(HvLds &S) { return *(HvLds::PeekD *)&S.ws[1]; }
 static HD void hv_cl_peek8(HvLds &S, const HevceImageDesc &im, int lane) {
-    if (lane) return;
-    const int k = S.cl_ans8 + 1, n8 = hv_n8(im);                 /* the CU of this round (its decision counts it) */
-    while (hv_poll(&S.c70_done) < 3 && !hv_peek(&S.cl_fail)) hv_spin_long();   /* (not before the chain's last 4x4 block: the answer is of no use earlier, and the polls share an L2 channel with every hand-off) */
-    for (;;) {
-        int all = 1, bw = 0, bc = 0;
-        for (int g = 0; g < n8; g++) {                           /* every 8x8 workgroup's answer; the best of them, on equal cost the higher candidate */
-            const unsigned long long t = hv_ld_flag64((const unsigned long long *)&im.cluster->res[2 + 2 * g + (k & 1)].tag);
-            all &= (((unsigned)t >> 8) & 0xffffff) == (unsigned)(k & 0xffffff);
-            const int w = (int)((unsigned)t & 0xff), c = (int)(t >> 32);
-            if (g == 0 || hv_w8_better(bc, bw, c, w)) { bw = w; bc = c; }
+    const int k = hv_uni(S.cl_ans8) + 1, n8 = hv_n8(im);         /* the CU of this round (its decision counts it) */
+    int got = 0;
+    if (lane == 0) {
+        while (hv_poll(&S.c70_done) < 3 && !hv_peek(&S.cl_fail)) hv_spin_long();   /* (not before the chain's last 4x4 block: the answer is of no use earlier, and the polls share an L2 channel with every hand-off) */
+        for (;;) {
+            int all = 1, bw = 0, bc = 0;
+            for (int g = 0; g < n8; g++) {                       /* every 8x8 workgroup's answer; the best of them, on equal cost the higher candidate */
+                const unsigned long long t = hv_ld_flag64((const unsigned long long *)&im.cluster->res[2 + 2 * g + (k & 1)].tag);
+                all &= (((unsigned)t >> 8) & 0xffffff) == (unsigned)(k & 0xffffff);
+                const int w = (int)((unsigned)t & 0xff), c = (int)(t >> 32);
+                if (g == 0 || hv_w8_better(bc, bw, c, w)) { bw = w; bc = c; }
+            }
+            if (all) {
+                hv_acquire_fence(S.cl_light);
+                S.pf.w = bw; S.pf.cost = bc; S.pf.k = k;
+                got = 1;
+                break;
+            }
+            if (hv_poll(&S.c70_done) >= 5 || hv_peek(&S.cl_fail)) break;
+            hv_spin_pause();
         }
-        if (all) {
-            hv_acquire_fence(S.cl_light);
-            S.pf.w = bw; S.pf.cost = bc; S.pf.k = k;
-            return;
-        }
-        if (hv_poll(&S.c70_done) >= 5 || hv_peek(&S.cl_fail)) return;
-        hv_spin_pause();
     }
+    WAVE_SYNC();
+    if (!hv_bcast0(got)) return;
+    /* ... and what the decision will want of that candidate if it beats the NxN one: its coder, contexts, samples, levels -- one round
+       trip to the L2 here, while the chain winds up, instead of at the start of the decision (hv_decide8_cluster) */
+    const int w = hv_min(hv_max(hv_uni(S.pf.w), 0), 69);
+    const HevceRes *r = &im.cluster->res[2 + 2 * hv_w8_owner(w, n8) + (k & 1)];
+    HV_GLOBAL u8 *scr = hv_worker8_scratch(im, k);
+    HvLds::PeekD &D = hv_pfd(S);
+    if (lane == 0) { D.range = hv_ldc_i32(&r->range); D.nbits = hv_ldc_i32(&r->nbits); }
+    for (int i = lane; i < HEVCE_NCTXP; i += 64) D.ctx[i] = (u8)hv_ldc_u8(&r->ctx[i]);
+    D.rec[lane] = (u8)hv_ldc_u8((const u8 *)(scr + HV_TL * 1024 * 2 + w * 1024 + lane));
+    D.lev[lane] = (short)hv_ldc_i16((const short *)scr + w * 1024 + lane);
+    WAVE_SYNC();
+    if (lane == 0) S.pf.dk = k;
 }
 static HD void hv_cl_report_nxn(HvLds &S, const HevceImageDesc &im, int lane);
 static HDN void hv_c70_rider(const HevceImageDesc &im, HV_GLOBAL u16 *c70, int q);

@@ -223,19 +223,39 @@ static HD void hv_tokcu(HvLds &S, HvW8 &W, HvLds::Level &L, HvGrp &G, int t, int
 template <typename ChunkPtr>
 static HD void hv_bengine(const HvLds &S, HvFCod &c, ChunkPtr sp, int n) {
     if (n <= 0) return;
+    /* sixteen tokens (one 16-byte chunk) per turn of the loop; the table entries of the NEXT four bins are fetched while four are coded,
+       into the other of two register sets (no moves), across the chunk boundary too */
+    unsigned al[4], an[4], bl[4], bn[4];
+#define HV_BENG_LOAD(L_, N_, WORD_) do { const unsigned wd_ = (WORD_); _Pragma("unroll") for (int k = 0; k < 4; k++) { const unsigned ix = (wd_ >> (8 * k)) & 0xffu; L_[k] = S.ctab2[ix][0]; N_[k] = S.ctab2[ix][1]; } } while (0)
+#define HV_BENG_RUN(L_, N_) do { _Pragma("unroll") for (int k = 0; k < 4; k++) hv_rengine_step(c, L_[k], N_[k]); } while (0)
     HvChunk cur = sp[0];
+    HV_BENG_LOAD(al, an, cur[0]);
     for (int base = 0; base < n; base += 16) {
-        const HvChunk nxt = sp[(base >> 4) + 1];
-#pragma unroll
-        for (int w4 = 0; w4 < 4; w4++) {
-            unsigned el[4], en[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) { const unsigned ix = (cur[w4] >> (8 * k)) & 0xffu; el[k] = S.ctab2[ix][0]; en[k] = S.ctab2[ix][1]; }
-#pragma unroll
-            for (int k = 0; k < 4; k++) hv_rengine_step(c, el[k], en[k]);
-        }
+        const HvChunk nxt = sp[(base >> 4) + 1];                 /* (at least 16 pad tokens behind the last one) */
+        HV_BENG_LOAD(bl, bn, cur[1]); HV_BENG_RUN(al, an);
+        HV_BENG_LOAD(al, an, cur[2]); HV_BENG_RUN(bl, bn);
+        HV_BENG_LOAD(bl, bn, cur[3]); HV_BENG_RUN(al, an);
+        HV_BENG_LOAD(al, an, nxt[0]); HV_BENG_RUN(bl, bn);
         cur = nxt;
     }
+#undef HV_BENG_LOAD
+#undef HV_BENG_RUN
+}
+/* the engines of a slot's four candidates, right behind their binarisation and on the same wavefront (the first lane of each mode slot):
+   they overlap the other wavefronts' work items -- one engine phase for all candidates behind a barrier took 16-24 k cycles of a CU's
+   ~60 k with seven of eight wavefronts' lanes idle.  Results where hv_pw_stage's arg-min expects them. */
+static HD void hv_w8_engine4(HvLds &S, HvW8 &W, int q, int t, int ok, int lane) {
+    HvLds::Level &L = S.lv[0];
+    WAVE_SYNC();                                                 /* the slot's tokens and counts are written */
+    if (ok && (lane & 15) == 0) {
+        HvFCod c = { S.ent[0].range, S.ent[0].nbits };
+        hv_bengine(S, c, (const HV_LDSP HvChunk *)W.tok[t], W.ntok[t]);
+        const int byp = W.nbyp[t];
+        L.tregs[t] = S.ent[0]; L.tregs[t].range = c.range; L.tregs[t].nbits = c.nbits;
+        L.tnlog[t] = byp; L.tdead[t] = 0; L.tpos[t] = -1;
+        L.tcost[t] = hv_rdcost(q, L.tsse[t], S.ent[0].nbits - c.nbits + byp);
+    }
+    WAVE_SYNC();
 }
 /* work item: the TU-split candidates 35 + 4 slot .. 35 + 4 slot + 3 -- per 4x4 block the reference samples from the candidate's own
    reconstruction, the block trial, the block's tokens  [ref :1455-1471] */
@@ -286,9 +306,10 @@ static HD void hv_w8_split_slot(HvLds &S, const HevceImageDesc &im, HvW8 &W, con
         W.tok[t][G.cur + ii] = (u8)(HV_PADCV << 1);
         if (ii == 0) { L.tsse[t] = total; W.ntok[t] = G.cur; W.nbyp[t] = G.byp; }
     }
+    hv_w8_engine4(S, W, q, t, ok, lane);
 }
 /* work item: the tokens of the single-block candidates 4 slot .. 4 slot + 3 (their block trials: hv_job_single<8>)  [ref :1434-1435] */
-static HD void hv_w8_single_slot(HvLds &S, HvW8 &W, int slot, HvGLev glev, int lane) {
+static HD void hv_w8_single_slot(HvLds &S, HvW8 &W, int q, int slot, HvGLev glev, int lane) {
     HvLds::Level &L = S.lv[0];
     const int ii = lane & 15, m0 = 4 * slot + (lane >> 4), ok = m0 < HEVCE_NMODES, t = ok ? m0 : 4 * slot;   /* (lanes without a mode: the slot's first one again -- its block trial is this workgroup's) */
     const int kind = hv_scan_kind(8, t);
@@ -309,6 +330,7 @@ static HD void hv_w8_single_slot(HvLds &S, HvW8 &W, int slot, HvGLev glev, int l
         W.tok[t][G.cur + ii] = (u8)(HV_PADCV << 1);
         if (ii == 0) { W.ntok[t] = G.cur; W.nbyp[t] = G.byp; }
     }
+    hv_w8_engine4(S, W, q, t, ok, lane);
 }
 /* all 70 candidates of the 8x8 CU: results where hv_pw_stage's arg-min expects them (L.tcost / tsse / tregs / tnlog / tctx) */
 /* clusters of six: which work items / candidates are 8x8 workgroup g's (items 0..4: single-block trials, 5..13: TU-split slots, 14..22: the
@@ -372,7 +394,7 @@ static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLe
             while (!hv_poll(&W.tdone[j0]) || !hv_poll(&W.tdone[j1])) hv_spin_short();
             HV_FENCE_ACQUIRE();
             HV_W8DBG(im, 4000 + id);
-            hv_w8_single_slot(S, W, slot, glev, lane);
+            hv_w8_single_slot(S, W, q, slot, glev, lane);
             HV_W8DBG(im, 5000 + id);
             HV_W8P(2);
         }
@@ -387,18 +409,7 @@ static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLe
 #ifdef HEVCE_EMU
     if (tid == 0 && getenv("HEVCE_EMU_W8") && cu.y == 0 && cu.x == 0) { fprintf(stderr, "emu ntok/nbyp:"); for (int t_ = 0; t_ < 70; t_++) fprintf(stderr, " (%d,%d)", W.ntok[t_], W.nbyp[t_]); fprintf(stderr, "\n"); }
 #endif
-    /* engines: one lane per candidate */
-    {
-        const int t = wave * 9 + lane;
-        if (lane < 9 && t < 70 && hv_w8_owner(t, n8) == g8) {
-            HvFCod c = { S.ent[0].range, S.ent[0].nbits };
-            hv_bengine(S, c, (const HV_LDSP HvChunk *)W.tok[t], W.ntok[t]);
-            const int byp = W.nbyp[t];
-            L.tregs[t] = S.ent[0]; L.tregs[t].range = c.range; L.tregs[t].nbits = c.nbits;
-            L.tnlog[t] = byp; L.tdead[t] = 0; L.tpos[t] = -1;
-            L.tcost[t] = hv_rdcost(q, L.tsse[t], S.ent[0].nbits - c.nbits + byp);
-        }
-    }
+    /* (the candidates' engines ran with their slots: hv_w8_engine4) */
     HV_W8DBG(im, 7500);
     BLOCK_SYNC();
     HV_W8Q(7);                                                   /* the candidates' engines */
