@@ -434,7 +434,7 @@ static HDN void hv_job_nxn(int wave, int lane, int q, HvCu cu, HV_GLOBAL u16 *c7
         HV_ARGMIN_STEP(hv_row_get<2>(cost), hv_row_get<2>(idx));
         HV_ARGMIN_STEP(hv_row_get<1>(cost), hv_row_get<1>(idx));
         {
-            const int c0 = hv_shfl(cost, 0), i0 = hv_shfl(idx, 0), c1 = hv_shfl(cost, 16), i1 = hv_shfl(idx, 16), c2 = hv_shfl(cost, 32), i2 = hv_shfl(idx, 32);
+            const int c0 = hv_readlane(cost, 0), i0 = hv_readlane(idx, 0), c1 = hv_readlane(cost, 16), i1 = hv_readlane(idx, 16), c2 = hv_readlane(cost, 32), i2 = hv_readlane(idx, 32);   /* (v_readlane: no trip through the LDS crossbar, and what follows is scalar) */
             cost = c0; idx = i0;
             HV_ARGMIN_STEP(c1, i1);
             HV_ARGMIN_STEP(c2, i2);                              /* (35 modes: the fourth row is empty) */
