@@ -253,7 +253,7 @@ static HD void hv_nxn_pass(HvLds &S, const HvPx4 &K, const HV_LDSP u16 *lut4, in
    A unit: slot | 0x20 = a whole pass, slot = its block trials (reported in S.nxq_tmask), slot | 0x10 = its binarisation (waits for them). */
 static constexpr unsigned char hv_nxq_sched[2][7][3] = {
     { { 0x28, 0xff, 0xff }, { 0x20, 0x21, 0xff }, { 0x22, 0x23, 0xff }, { 0x24, 0x25, 0xff }, { 0x26, 0x27, 0xff }, { 0xff, 0xff, 0xff }, { 0xff, 0xff, 0xff } },
-    { { 0x28, 0xff, 0xff }, { 0x06, 0x20, 0xff }, { 0x07, 0x21, 0xff }, { 0x22, 0x16, 0xff }, { 0x23, 0x17, 0xff }, { 0x24, 0xff, 0xff }, { 0x25, 0xff, 0xff } } };
+    { { 0x28, 0x17, 0xff }, { 0x20, 0x16, 0xff }, { 0x07, 0x21, 0xff }, { 0x06, 0x22, 0xff }, { 0x23, 0xff, 0xff }, { 0x24, 0xff, 0xff }, { 0x25, 0xff, 0xff } } };
 static HD void hv_nxq_units(HvLds &S, const HvPx4 &K, const HV_LDSP u16 *lut4, int q, int ty, int tx, int six, int who, int lane) {   /* who: 0 = the chain wavefront, 1 + h = helper h */
 #if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
     const unsigned long long u0_ = __builtin_amdgcn_s_memtime();

@@ -247,6 +247,9 @@ static HD void hv_bengine(const HvLds &S, HvFCod &c, ChunkPtr sp, int n) {
 static HD void hv_w8_engine4(HvLds &S, HvW8 &W, int q, int t, int ok, int lane) {
     HvLds::Level &L = S.lv[0];
     WAVE_SYNC();                                                 /* the slot's tokens and counts are written */
+#if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
+    const unsigned long long e0_ = __builtin_amdgcn_s_memtime();
+#endif
     if (ok && (lane & 15) == 0) {
         HvFCod c = { S.ent[0].range, S.ent[0].nbits };
         hv_bengine(S, c, (const HV_LDSP HvChunk *)W.tok[t], W.ntok[t]);
@@ -256,6 +259,9 @@ static HD void hv_w8_engine4(HvLds &S, HvW8 &W, int q, int t, int ok, int lane) 
         L.tcost[t] = hv_rdcost(q, L.tsse[t], S.ent[0].nbits - c.nbits + byp);
     }
     WAVE_SYNC();
+#if defined(HEVCE_PROF) && !defined(HEVCE_PROF_LIGHT) && !defined(HEVCE_EMU)
+    if (lane == 0) { S.prof2[7] += __builtin_amdgcn_s_memtime() - e0_; S.prof2[6] += (unsigned long long)W.ntok[t]; }   /* (probe: all of the workgroup's slots; lane 0's candidate's tokens) */
+#endif
 }
 /* work item: the TU-split candidates 35 + 4 slot .. 35 + 4 slot + 3 -- per 4x4 block the reference samples from the candidate's own
    reconstruction, the block trial, the block's tokens  [ref :1455-1471] */
@@ -401,7 +407,7 @@ static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLe
     }
     HV_W8DBG(im, 6000);
     BLOCK_SYNC();
-    HV_W8Q(6);                                                   /* the work items, to the last wavefront's end */
+    /* (probe slots 6 / 7 now: tokens and cycles of the slots' engines, hv_w8_engine4) */
     HV_W8DBG(im, 7000);
 #if defined(HEVCE_W8DBG) && !defined(HEVCE_EMU)
     if (im.trace && lane < 9 && wave * 9 + lane < 70) { ((volatile int *)im.trace)[128 + wave * 9 + lane] = W.ntok[wave * 9 + lane]; __threadfence_system(); }
@@ -412,7 +418,7 @@ static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLe
     /* (the candidates' engines ran with their slots: hv_w8_engine4) */
     HV_W8DBG(im, 7500);
     BLOCK_SYNC();
-    HV_W8Q(7);                                                   /* the candidates' engines */
+
     HV_W8DBG(im, 7600);
 }
 

@@ -42,7 +42,7 @@ if kind == "phases":
     wk = tr[160:176].view(np.uint64).astype(float)
     if wk[5] > 0:
         print("  8x8 worker (cluster >= 4), k cycles per message: wait %.1f, accept %.1f, jobs %.1f, contexts+binarise %.1f, engines+answer %.1f" % tuple(wk[i] / wk[5] / 1e3 for i in range(5)))
-        print("    of the jobs stage: work items (to the last wavefront's end) %.1f, the candidates' engines %.1f   (HEVCE_FLAGS bit 5: the second 8x8 workgroup's numbers)" % (wk[6] / wk[5] / 1e3, wk[7] / wk[5] / 1e3))
+        print("    the slots' engines (four candidates each, behind the slot's binarisation): %.1f k cycles per CU in all, %.0f tokens (first candidate of each slot) per CU   (HEVCE_FLAGS bit 5: the second 8x8 workgroup's numbers)" % (wk[7] / wk[5] / 1e3, wk[6] / wk[5]))
         pw = tr[160:224].view(np.uint64).astype(float)[8:32].reshape(8, 3) / wk[5] / 1e3
         for wv in range(8):
             print("    wavefront %d: single-block trial items %.1f, TU-split slots (trials + tokens) %.1f, single-block token slots %.1f   (k cycles per CU; work items are handed out by a counter)" % (wv, pw[wv, 0], pw[wv, 1], pw[wv, 2]))
