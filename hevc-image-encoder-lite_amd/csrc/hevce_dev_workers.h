@@ -348,7 +348,6 @@ static HD int hv_w8_mine_item(int id, int g, int n8) {
 }
 static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLev glev, HvGRec grec, int g8) {
     const int tid = hv_tid(), wave = tid >> 6, lane = tid & 63, q = im.qpd6;
-    HvLds::Level &L = S.lv[0];
     HvW8 &W = hv_w8(S);
     const int n8 = hv_n8(im);
 #ifdef HEVCE_EMU
