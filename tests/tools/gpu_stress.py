@@ -3,7 +3,7 @@
 C ABI, every stream and reconstruction compared with the oracle (CPU restatement; test infrastructure).  The kernel's
 wavefronts hand work to each other through LDS flags and idle-time riding, i.e. its timing varies from launch to launch:
 this sweep is there to catch what a fixed set of goldens cannot.  usage: gpu_stress.py [n_pictures] [seed] [repeats] [batch]
-batch: pictures per launch (default: all in one).  Launches of at most 64 pictures run as clusters of four workgroups per picture
+batch: pictures per launch (default: all in one).  Launches of at most 32 pictures run as clusters of seven workgroups per picture (fewer workgroups up to 128 pictures)
 (hevce_device.h cluster mode), larger ones with one workgroup per picture; the consistency counter of every picture
 (hevce_job_stats: a state mismatch that the re-analysis healed) must stay 0 too."""
 import os, sys, time, json
