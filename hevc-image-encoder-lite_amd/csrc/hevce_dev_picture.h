@@ -150,11 +150,12 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                     if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + S.lv[2].split_inc, 1);
                     BLOCK_SYNC();
                 }
+                const int quad_first = cl8 && step < 20 && m == 0;   /* clusters of four and more: the quad's message goes out BEFORE the 16x16 CU's (below) */
                 if (step < 20 && m == 0) {                       /* entering a 16x16 CU */
                     hv_snapshot(S, 1, tid);
                     hv_level_begin(S, c16);
                     BLOCK_SYNC();
-                    if (cl) hv_cl_send(S, im, c16, ctu, 1);
+                    if (cl && !quad_first) hv_cl_send(S, im, c16, ctu, 1);
                     if (tid == 0) hv_commit_bin(S, CX_SPLIT_CU + S.lv[1].split_inc, 1);
                     BLOCK_SYNC();
                 }
@@ -167,7 +168,12 @@ static HD void hv_analyse_image(HvLds &S, const HevceImageDesc &im) {
                         if (tid < 70) { S.lv[0].tdead[tid] = 1; S.lv[0].tpos[tid] = -1; }
                         if (tid == 0) S.l0_active = 1;
                         HV_PROFC(S, 5);                          /* since the last 8x8 decision: enclosing CUs' decisions and entries, snapshot, level begin */
-                        if (m == 0) hv_cl_send(S, im, cu, ctu, 1, &c16);   /* opens the quad; the 8x8 workgroup finds its way through the other three CUs */
+                        if (m == 0) {
+                            hv_cl_send(S, im, cu, ctu, 1, &c16);   /* opens the quad; the 8x8 workgroups find their way through the other three CUs */
+                            /* ... and only now the 16x16 CU's own message (its entry snapshot, S.ent[1], is from before the split flag): the 8x8
+                               workgroups' first CU of a quad is what the chain waits for, the 16x16 answer is due four rounds later */
+                            if (quad_first) hv_cl_send(S, im, c16, ctu, 1);
+                        }
                         else BLOCK_SYNC();
                         HV_PROFC(S, 6);
                     }
