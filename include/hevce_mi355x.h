@@ -97,12 +97,20 @@ int  hevce_job_timings(hevce_job *job, float *kernel_ms, float *d2h_ms, float *w
 
 /* The kernel analyses with range-only ("FAST") trial coders and re-analyses with the exact ones the few CTUs whose bit counts
    an emulation-prevention byte could have changed; stats: out2[0] = CTUs of image i analysed twice in the last
-   run, out2[1] = coder consistency failures (always 0).  flags (tests): bit 0 = exact coders throughout, bit 1 = one workgroup
-   per picture even when two would fit (no cluster mode), bits 8-15 / 16-23 = force a re-analysis every k-th CTU through either
-   detection path. */
+   run, out2[1] = coder consistency failures (always 0).  flags (tests and comparisons; 0 for production):
+     bit 0        exact coders throughout (the reference's bit counts by construction; ~2.4 x slower)
+     bit 1        one workgroup per picture even when a cluster would fit
+     bit 2        the cluster's worker workgroups leave at once without reporting alive: exercises the residency check and the fall-back
+     bit 3        clusters of four and five: the round-2 path of the 8x8 workgroup (one block job per wavefront)
+     bit 4        agent-scope (HEAVY) fences for every hand-off between a cluster's workgroups, also on one XCD
+     bit 5        probe builds: report the second 8x8 workgroup's cycle counters instead of the first one's
+     bit 6        clusters of five and more: the writer workgroup runs the shared-compute-unit coder (hv_wr_engine) instead of its own
+     bits 8-15 / 16-23   force a re-analysis every k-th CTU through the NxN-verification / the stream-writer detection path
+     bits 24-26   with bits 16-23 in clusters of five and more: how many CTUs the forced report lies back (roll-back depth) */
 int  hevce_job_set_flags(hevce_job *job, int flags);
-/* workgroups per picture the next launch uses (1 = no clusters); *fallbacks (may be NULL) = launches that had to be repeated without
-   clusters because a hand-off timed out.  Flag bit 2 (tests) makes the cluster's workers leave at once, which exercises that path. */
+/* workgroups per picture of the last launch (before the first: what the device has room for; 1 = no clusters); *fallbacks (may be NULL) =
+   launches that had to be repeated without clusters because a cluster was not placed (the kernel's alive check, milliseconds) or a
+   hand-off timed out.  The size of a launch is what fits beside this process's other launches in flight. */
 int  hevce_job_cluster(hevce_job *job, int *fallbacks);
 int  hevce_job_stats(hevce_job *job, int i, int *out2);
 
