@@ -338,6 +338,20 @@ static HD void hv_w8_single_slot(HvLds &S, HvW8 &W, int q, int slot, HvGLev glev
     }
     hv_w8_engine4(S, W, q, t, ok, lane);
 }
+/* the two slot items as functions of their own (not inlined into the kernel's body: its register allocation is fragile enough, see
+   experiments/README.md round 3) */
+static HDN void hv_w8_split_slot_fn(const HevceImageDesc &im, HvCu cu, int slot, HvGLev glev, HvGRec grec) {
+    HvLds &S = HV_S;
+    const int lane = hv_tid() & 63;
+    cu.y = hv_uni(cu.y); cu.x = hv_uni(cu.x); slot = hv_uni(slot);
+    HvPx4 K;
+    hv_px4_consts(S, K, lane);
+    hv_w8_split_slot(S, im, hv_w8(S), K, cu, slot, glev, grec, lane);
+}
+static HDN void hv_w8_single_slot_fn(int q, int slot, HvGLev glev) {
+    HvLds &S = HV_S;
+    hv_w8_single_slot(S, hv_w8(S), hv_uni(q), hv_uni(slot), glev, hv_tid() & 63);
+}
 /* all 70 candidates of the 8x8 CU: results where hv_pw_stage's arg-min expects them (L.tcost / tsse / tregs / tnlog / tctx) */
 /* clusters of six: which work items / candidates are 8x8 workgroup g's (items 0..4: single-block trials, 5..13: TU-split slots, 14..22: the
    single-block candidates' tokens) */
@@ -392,14 +406,14 @@ static HD void hv_w8_cu(HvLds &S, const HevceImageDesc &im, const HvCu cu, HvGLe
             WAVE_SYNC();
             hv_flag_set(&W.tdone[id], 1);                        /* (every lane stores the same value: no one-lane region here) */
             HV_W8P(0);
-        } else if (id < 14) { hv_w8_split_slot(S, im, W, K, cu, id - 5, glev, grec, lane); HV_W8DBG(im, 2500 + id); HV_W8P(1); }
+        } else if (id < 14) { hv_w8_split_slot_fn(im, cu, id - 5, glev, grec); HV_W8DBG(im, 2500 + id); HV_W8P(1); }
         else {
             const int slot = id - 14, j0 = (4 * slot) >> 3, j1 = hv_min(4 * slot + 3, 34) >> 3;
             HV_W8DBG(im, 3000 + id);
             while (!hv_poll(&W.tdone[j0]) || !hv_poll(&W.tdone[j1])) hv_spin_short();
             HV_FENCE_ACQUIRE();
             HV_W8DBG(im, 4000 + id);
-            hv_w8_single_slot(S, W, q, slot, glev, lane);
+            hv_w8_single_slot_fn(q, slot, glev);
             HV_W8DBG(im, 5000 + id);
             HV_W8P(2);
         }

@@ -3,6 +3,12 @@
  */
 #include "hevce_device.h"
 
+/* The roles of a cluster are functions of their own (not inlined into the kernel): each gets its own register allocation, so that a change
+   in the workers' code does not move spill code into the chain's loops (experiments/README.md, round 3). */
+static __device__ __noinline__ void hv_role_chain(const HevceImageDesc &im) { hv_analyse_image(HV_S, im); }
+static __device__ __noinline__ void hv_role_writer(const HevceImageDesc &im) { hv_writer_worker(HV_S, im); }
+static __device__ __noinline__ void hv_role_worker(const HevceImageDesc &im, int serve, int g8) { hv_parent_worker(HV_S, im, serve, g8); }
+
 extern "C" __global__ void __launch_bounds__(HV_NTHREADS, 2)
 hevce_analyse_kernel(const HevceImageDesc *__restrict__ images, int nimages, int cluster) {
     /* cluster mode: `cluster` (2 .. 4) workgroups per picture -- the first walks the picture's chain of decisions, the others
@@ -13,12 +19,12 @@ hevce_analyse_kernel(const HevceImageDesc *__restrict__ images, int nimages, int
     const int pic = cluster > 1 ? b % npad : b, role = cluster > 1 ? b / npad : 0;
     if (pic >= nimages) return;
     const HevceImageDesc im = images[pic];
-    if (role == 0) hv_analyse_image(HV_S, im);
-    else if (role == 4) hv_writer_worker(HV_S, im);              /* clusters of five: the stream writer */
-    else if (role == 3) hv_parent_worker(HV_S, im, 4, 0);
-    else if (role == 5) hv_parent_worker(HV_S, im, 4, 1);       /* clusters of six: the second 8x8 workgroup */
-    else if (role == 6) hv_parent_worker(HV_S, im, 4, 2);       /* clusters of seven: the third */
-    else hv_parent_worker(HV_S, im, cluster == 2 ? 3 : role);
+    if (role == 0) hv_role_chain(im);
+    else if (role == 4) hv_role_writer(im);                      /* clusters of five: the stream writer */
+    else if (role == 3) hv_role_worker(im, 4, 0);
+    else if (role == 5) hv_role_worker(im, 4, 1);               /* clusters of six: the second 8x8 workgroup */
+    else if (role == 6) hv_role_worker(im, 4, 2);               /* clusters of seven: the third */
+    else hv_role_worker(im, cluster == 2 ? 3 : role, 0);
 }
 
 /* host-side launcher used by hevce_host.cpp: grid = images of the batch (times the cluster size) */
