@@ -276,19 +276,22 @@ static HD void hv_w8_split_slot(HvLds &S, const HevceImageDesc &im, HvW8 &W, con
         int l, lb, a, ar;
         hv_sub_avail(b, cu.L, cu.LB, cu.A, cu.AR, l, lb, a, ar);
         const int oy = (b >> 1) * 4, ox = (b & 1) * 4, ty = cu.y + oy, tx = cu.x + ox;
-        /* reference samples: inside the CU the candidate's own reconstruction  [ref :196-257 for a 4x4 block] */
+        /* reference samples: inside the CU the candidate's own reconstruction  [ref :196-257 for a 4x4 block].  Lanes 0..7 of the mode the
+           left column downwards, 8..15 the row above: one position each (and the corner), both possible sources read and one selected */
         {
             auto px = [&](int yy, int xx) -> int {
-                const int ry = yy - cu.y, rx = xx - cu.x;
-                return (ry >= 0 && ry < 8 && rx >= 0 && rx < 8) ? W.crec[m][ry * 8 + rx] : S.rec[yy + 1][xx + HV_RX];
+                const int ry = yy - cu.y, rx = xx - cu.x, in = ry >= 0 && ry < 8 && rx >= 0 && rx < 8;
+                const int vi = W.crec[m][hv_min(hv_max(ry, 0), 7) * 8 + hv_min(hv_max(rx, 0), 7)], vo = S.rec[yy + 1][xx + HV_RX];
+                return in ? vi : vo;
             };
-            const int corner = (l && a) ? px(ty - 1, tx - 1) : (l ? px(ty, tx - 1) : (a ? px(ty - 1, tx) : 128));
-            const int i8 = ii & 7;
-            int vl = l ? px(ty + hv_min(i8, 3), tx - 1) : corner, va = a ? px(ty - 1, tx + hv_min(i8, 3)) : corner;
-            if (i8 >= 4) { vl = lb ? px(ty + i8, tx - 1) : vl; va = ar ? px(ty - 1, tx + i8) : va; }
+            const int cy_ = (l && a) ? ty - 1 : (l ? ty : ty - 1), cx_ = (l && a) ? tx - 1 : (l ? tx - 1 : tx);
+            const int corner = (l || a) ? px(cy_, cx_) : 128;
+            const int side = ii >= 8, i8 = ii & 7, on = side ? a : l, on2 = side ? ar : lb;
+            const int k = (i8 < 4 || on2) ? i8 : 3;                               /* second four missing: the fourth one again */
+            const int v = on ? px(side ? ty - 1 : ty + k, side ? tx + k : tx - 1) : corner;
             const int mb = ok ? m : 35;
             WAVE_SYNC();
-            if (ii < 8) W.bord[mb][1 + i8] = (u8)vl; else W.bord[mb][9 + i8] = (u8)va;
+            W.bord[mb][1 + ii] = (u8)v;                                           /* (left[8] at 1.., above[8] at 9..) */
             if (ii == 0) W.bord[mb][0] = (u8)corner;
             WAVE_SYNC();
         }
@@ -501,11 +504,20 @@ static HD void hv_pw_stage(HvLds &S, const HevceImageDesc &im, const HvCu cu, in
             const bool take = ok && (bi == -2 || c < bc || (c == bc && t > bi));
             bc = take ? c : bc; bi = take ? t : bi;
         }
-        for (int sft = 1; sft < 64; sft <<= 1) {
-            const int oc = hv_shfl_xor(bc, sft), oi = hv_shfl_xor(bi, sft);
-            const bool take = oi != -2 && (bi == -2 || oc < bc || (oc == bc && oi > bi));
-            bc = take ? oc : bc; bi = take ? oi : bi;
+        /* (inside the rows of sixteen by DPP rotations, then the four rows' results by v_readlane: six rounds of two LDS-crossbar shuffles
+           each took ~0.5 k cycles more, of an answer that is on the chain's critical path at the start of a quad) */
+#define HV_AM_STEP(OC, OI) do { const int oc_ = (OC), oi_ = (OI); const bool tk_ = oi_ != -2 && (bi == -2 || oc_ < bc || (oc_ == bc && oi_ > bi)); bc = tk_ ? oc_ : bc; bi = tk_ ? oi_ : bi; } while (0)
+        HV_AM_STEP(hv_row_get<8>(bc), hv_row_get<8>(bi));
+        HV_AM_STEP(hv_row_get<4>(bc), hv_row_get<4>(bi));
+        HV_AM_STEP(hv_row_get<2>(bc), hv_row_get<2>(bi));
+        HV_AM_STEP(hv_row_get<1>(bc), hv_row_get<1>(bi));
+        {
+            const int c0 = hv_readlane(bc, 0), i0 = hv_readlane(bi, 0), c1 = hv_readlane(bc, 16), i1 = hv_readlane(bi, 16);
+            const int c2 = hv_readlane(bc, 32), i2 = hv_readlane(bi, 32), c3 = hv_readlane(bc, 48), i3 = hv_readlane(bi, 48);
+            bc = c0; bi = i0;
+            HV_AM_STEP(c1, i1); HV_AM_STEP(c2, i2); HV_AM_STEP(c3, i3);
         }
+#undef HV_AM_STEP
         if (tid == 0) S.winner = bi;                             /* for hv_pw_advance8, behind the barrier below */
         const int w = hv_min(hv_max(hv_bcast0(bi), 0), 69);
         const int k8 = hv_uni(S.cl_ans8) + 1;                     /* 8x8: this is the answer to CU number k8 of the launch */
