@@ -59,9 +59,14 @@ def test_emulated_kernel_reanalysis_paths(path, flags):
     assert (redo > 0) == (flags != 1)
 
 
-@pytest.mark.parametrize("nwg", [2, 3, 4, 5, 6, 7])
-@pytest.mark.parametrize("flags", [0, 2 << 8, 3 << 16, (3 << 16) | (4 << 24)], ids=["fast", "nxn2", "wr3", "wr3-back5"])
-@pytest.mark.parametrize("path", MODE_CASES, ids=lambda p: os.path.basename(p)[6:-4])
+_CL_FLAGS = [(0, "fast"), (2 << 8, "nxn2"), (3 << 16, "wr3"), ((3 << 16) | (4 << 24), "wr3-back5")]
+# every picture x every re-analysis path on the two sizes that ship as defaults (4: round 2's, 7: this round's); the sizes in between
+# (each adds one role) on one picture: the CPU suite has to stay within minutes, the GPU suite runs the clusters on real pictures
+_CL_CASES = [pytest.param(p, f, n, id=f"{os.path.basename(p)[6:-4]}-{fid}-{n}")
+             for n in (2, 3, 4, 5, 6, 7) for (f, fid) in _CL_FLAGS for p in (MODE_CASES if n in (4, 7) else MODE_CASES[:1])]
+
+
+@pytest.mark.parametrize("path,flags,nwg", _CL_CASES)
 def test_emulated_cluster_of_workgroups(path, flags, nwg):
     """cluster mode (hevce_dev_workers.h hv_parent_worker): the chain workgroup and the parent workgroup(s) of one picture as 2 / 3 / 4 x 512
     fibers exchanging messages through the HevceCluster mailboxes; also with re-analysed CTUs, which the chain workgroup does alone."""
